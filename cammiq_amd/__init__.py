@@ -1,0 +1,8 @@
+"""cammiq_amd -- MI355X-native engine for CAMMiQ's read-classification hot path.
+
+The product is ``libcammiq_hip.so`` (C ABI in ``include/cammiq_hip.h``, sources in
+``cammiq_amd/csrc``) and the ``cammiq`` command-line shell built on it.  This package is
+the thin Python binding used by tests and bench.py, plus synthetic-input helpers.
+"""
+from .binding import (CammiqError, Index, MODE_P, MODE_SC, lib, lib_path, pack_reads,  # noqa: F401
+                      stride_words)

@@ -1,0 +1,399 @@
+// cq_api.cpp -- the C ABI of libcammiq_hip.so (see include/cammiq_hip.h).
+//
+// Host-side replacement of the seam the reference has at FqReader::loadIdx_p
+// (/root/reference/src/query.cpp:109-123) and FqReader::query64_p / query64mt_p / query64_sc
+// (query.cpp:458-1080): load + lay out + upload the index, then run the HIP classify
+// kernels on reads and hand the counters back.  No CPU classify path exists here.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "cq_index.hpp"
+#include "cq_kernels.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string &msg)
+{
+    g_err = msg;
+    return code;
+}
+
+#define CQ_HIP(call)                                                                            \
+    do {                                                                                        \
+        hipError_t e_ = (call);                                                                 \
+        if (e_ != hipSuccess)                                                                   \
+            return fail(e_ == hipErrorNoDevice || e_ == hipErrorInvalidDevice ? CQ_ERR_NO_DEVICE \
+                                                                             : CQ_ERR_HIP,      \
+                        std::string(#call) + ": " + hipGetErrorString(e_));                     \
+    } while (0)
+
+constexpr uint32_t kPairCap = 1u << 20;
+
+}  // namespace
+
+struct cq_index {
+    cq::DecodedTable tab[2];
+    cq::FlatImage img;
+    uint64_t n_file_buckets[2] = {0, 0};
+    uint32_t doubly_flag[2] = {0, 1};
+    int device = CQ_DEVICE_NONE;
+    int n_cus = 0;
+    uint64_t device_bytes = 0;
+    // device image
+    void *d_slots = nullptr, *d_nodes = nullptr, *d_leaf_rids = nullptr;
+    cq::DevIndex dev{};
+    // per-handle workspace (grown on demand, reused across calls)
+    uint32_t *d_ovf_list = nullptr, *d_ovf_count = nullptr;
+    uint64_t ovf_cap = 0;
+    uint64_t *d_pair_keys = nullptr, *d_pair_cnts = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool ev_valid = false;
+};
+
+namespace {
+
+void release_device(cq_index *ix)
+{
+    if (ix->device < 0) return;
+    (void)hipSetDevice(ix->device);
+    if (ix->d_slots) (void)hipFree(ix->d_slots);
+    if (ix->d_nodes) (void)hipFree(ix->d_nodes);
+    if (ix->d_leaf_rids) (void)hipFree(ix->d_leaf_rids);
+    if (ix->d_ovf_list) (void)hipFree(ix->d_ovf_list);
+    if (ix->d_ovf_count) (void)hipFree(ix->d_ovf_count);
+    if (ix->d_pair_keys) (void)hipFree(ix->d_pair_keys);
+    if (ix->d_pair_cnts) (void)hipFree(ix->d_pair_cnts);
+    if (ix->ev0) (void)hipEventDestroy(ix->ev0);
+    if (ix->ev1) (void)hipEventDestroy(ix->ev1);
+}
+
+int upload(cq_index *ix)
+{
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0) return fail(CQ_ERR_NO_DEVICE, "no HIP device available");
+    if (ix->device >= ndev) return fail(CQ_ERR_NO_DEVICE, "device ordinal out of range");
+    CQ_HIP(hipSetDevice(ix->device));
+    hipDeviceProp_t prop;
+    CQ_HIP(hipGetDeviceProperties(&prop, ix->device));
+    ix->n_cus = prop.multiProcessorCount;
+    const cq::FlatImage &img = ix->img;
+    const size_t sb = img.slots.size() * sizeof(cq_slot);
+    const size_t nb = img.nodes.size() * sizeof(cq::Node);
+    const size_t nl = img.leaf_r1.size();
+    CQ_HIP(hipMalloc(&ix->d_slots, sb));
+    CQ_HIP(hipMalloc(&ix->d_nodes, nb));
+    CQ_HIP(hipMalloc(&ix->d_leaf_rids, std::max<size_t>(nl, 1) * sizeof(uint2)));
+    CQ_HIP(hipMemcpy(ix->d_slots, img.slots.data(), sb, hipMemcpyHostToDevice));
+    CQ_HIP(hipMemcpy(ix->d_nodes, img.nodes.data(), nb, hipMemcpyHostToDevice));
+    {
+        std::vector<uint2> rr(nl);
+        for (size_t i = 0; i < nl; i++) rr[i] = make_uint2(img.leaf_r1[i], img.leaf_r2[i]);
+        if (nl) CQ_HIP(hipMemcpy(ix->d_leaf_rids, rr.data(), nl * sizeof(uint2), hipMemcpyHostToDevice));
+    }
+    CQ_HIP(hipMalloc((void **)&ix->d_ovf_count, sizeof(uint32_t)));
+    CQ_HIP(hipMalloc((void **)&ix->d_pair_keys, (size_t)kPairCap * 8));
+    CQ_HIP(hipMalloc((void **)&ix->d_pair_cnts, (size_t)kPairCap * 8));
+    CQ_HIP(hipMemset(ix->d_pair_keys, 0xFF, (size_t)kPairCap * 8));
+    CQ_HIP(hipMemset(ix->d_pair_cnts, 0, (size_t)kPairCap * 8));
+    CQ_HIP(hipEventCreate(&ix->ev0));
+    CQ_HIP(hipEventCreate(&ix->ev1));
+    ix->device_bytes = sb + nb + nl * sizeof(uint2) + (size_t)kPairCap * 16;
+    ix->dev.slots = (const uint4 *)ix->d_slots;
+    ix->dev.nodes = (const uint4 *)ix->d_nodes;
+    ix->dev.leaf_rids = (const uint2 *)ix->d_leaf_rids;
+    ix->dev.n_buckets = (uint32_t)img.n_buckets;
+    ix->dev.hash_len = img.hash_len;
+    return CQ_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int cq_abi_version(void) { return CQ_ABI_VERSION; }
+
+const char *cq_last_error(void) { return g_err.c_str(); }
+
+int cq_index_load(const char *path_u, const char *path_d, int device, cq_index **out)
+{
+    if (!path_u || !out || device < CQ_DEVICE_NONE) return fail(CQ_ERR_ARG, "cq_index_load: bad argument");
+    *out = nullptr;
+    cq_index *ix = new (std::nothrow) cq_index();
+    if (!ix) return fail(CQ_ERR_NOMEM, "out of memory");
+    const bool have_d = path_d && path_d[0];
+    // The reference loads the two files on two pthreads (query.cpp:112-116); same here.
+    int rc_u = CQ_OK, rc_d = CQ_OK;
+    std::string err_u, err_d;
+    try {
+        std::thread td;
+        if (have_d) td = std::thread([&] { rc_d = cq::decode_table(path_d, ix->tab[1], err_d); });
+        rc_u = cq::decode_table(path_u, ix->tab[0], err_u);
+        if (have_d) td.join();
+        if (rc_u != CQ_OK) { delete ix; return fail(rc_u, err_u); }
+        if (rc_d != CQ_OK) { delete ix; return fail(rc_d, err_d); }
+        if (!have_d) cq::make_empty_table(ix->tab[0].hash_len, ix->tab[1]);
+        for (int t = 0; t < 2; t++) {
+            ix->n_file_buckets[t] = ix->tab[t].n_file_buckets;
+            ix->doubly_flag[t] = ix->tab[t].doubly;
+        }
+        std::string err;
+        int rc = cq::build_image(ix->tab[0], ix->tab[1], 1.5, ix->img, err);
+        if (rc != CQ_OK) { delete ix; return fail(rc, err); }
+        // bucket/node arrays of the decode stage are no longer needed; leaves are (cq_index_leaves)
+        for (int t = 0; t < 2; t++) {
+            std::vector<uint64_t>().swap(ix->tab[t].bucket_key);
+            std::vector<uint32_t>().swap(ix->tab[t].bucket_code);
+            std::vector<cq::Node>().swap(ix->tab[t].nodes);
+        }
+    } catch (const std::bad_alloc &) {
+        delete ix;
+        return fail(CQ_ERR_NOMEM, "out of memory while loading the index");
+    }
+    ix->device = device;
+    if (device >= 0) {
+        int rc = upload(ix);
+        if (rc != CQ_OK) { release_device(ix); delete ix; return rc; }
+    }
+    *out = ix;
+    return CQ_OK;
+}
+
+int cq_index_get_info(const cq_index *ix, cq_index_info *info)
+{
+    if (!ix || !info) return fail(CQ_ERR_ARG, "cq_index_get_info: NULL argument");
+    memset(info, 0, sizeof *info);
+    info->abi_version = CQ_ABI_VERSION;
+    info->hash_len = ix->img.hash_len;
+    info->max_refid = ix->img.max_refid;
+    info->device = ix->device;
+    for (int t = 0; t < 2; t++) {
+        info->doubly_flag[t] = ix->doubly_flag[t];
+        info->n_leaves[t] = ix->img.n_leaves[t];
+        info->n_file_buckets[t] = ix->n_file_buckets[t];
+    }
+    info->n_trie_nodes = ix->img.nodes.size() - 1;
+    info->n_keys = ix->img.n_keys;
+    info->n_table_buckets = ix->img.n_buckets_alloc;
+    info->n_overflowed = ix->img.n_overflowed;
+    info->max_chain = ix->img.max_chain;
+    info->device_bytes = ix->device_bytes;
+    return CQ_OK;
+}
+
+int cq_index_leaves(const cq_index *ix, int table, cq_leaf *out)
+{
+    if (!ix || !out || table < 0 || table > 1) return fail(CQ_ERR_ARG, "cq_index_leaves: bad argument");
+    const auto &lv = ix->tab[table].leaves;
+    if (!lv.empty()) memcpy(out, lv.data(), lv.size() * sizeof(cq_leaf));
+    return CQ_OK;
+}
+
+int cq_index_probe(const cq_index *ix, uint64_t hv, uint32_t *code_u, uint32_t *code_d, uint32_t *chain)
+{
+    if (!ix || !code_u || !code_d) return fail(CQ_ERR_ARG, "cq_index_probe: NULL argument");
+    if (ix->img.slots.empty()) return fail(CQ_ERR_ARG, "cq_index_probe: host image was released");
+    cq::image_lookup(ix->img, hv, *code_u, *code_d, chain);
+    return CQ_OK;
+}
+
+void cq_index_free(cq_index *ix)
+{
+    if (!ix) return;
+    release_device(ix);
+    delete ix;
+}
+
+uint64_t cq_counter_words(uint32_t n_genomes) { return 2ull * ((uint64_t)n_genomes + 1) + CQ_CTR_EXTRA; }
+
+int cq_query_device(cq_index *ix, int mode, const uint32_t *d_packed, const uint8_t *d_lens,
+                    uint64_t n_reads, uint32_t stride_words, uint32_t max_len, uint32_t n_genomes,
+                    uint64_t *d_counters, uint32_t *d_rcount, void *stream)
+{
+    if (!ix) return fail(CQ_ERR_ARG, "cq_query_device: NULL handle");
+    if (ix->device < 0) return fail(CQ_ERR_NO_DEVICE, "index was loaded host-only (CQ_DEVICE_NONE); no CPU classify path exists");
+    if (mode != CQ_MODE_P && mode != CQ_MODE_SC) return fail(CQ_ERR_ARG, "cq_query_device: unknown mode");
+    if (!d_counters || (n_reads && (!d_packed || !d_lens)) || stride_words == 0 || (stride_words & 3u) || stride_words > 16)
+        return fail(CQ_ERR_ARG, "cq_query_device: bad argument");
+    if (n_reads > 0x7FFFFFFFull) return fail(CQ_ERR_ARG, "cq_query_device: more than 2^31-1 reads in one call");
+    if (ix->img.max_refid > n_genomes)
+        return fail(CQ_ERR_RANGE, "index holds refID " + std::to_string(ix->img.max_refid) + " > n_genomes");
+    if (n_reads == 0) return CQ_OK;
+    hipStream_t st = (hipStream_t)stream;
+    CQ_HIP(hipSetDevice(ix->device));
+    if (ix->ovf_cap < n_reads) {   // grow the slow-path list (outside steady state)
+        if (ix->d_ovf_list) CQ_HIP(hipFree(ix->d_ovf_list));
+        ix->d_ovf_list = nullptr;
+        CQ_HIP(hipMalloc((void **)&ix->d_ovf_list, n_reads * sizeof(uint32_t)));
+        ix->ovf_cap = n_reads;
+    }
+    CQ_HIP(hipMemsetAsync(ix->d_ovf_count, 0, sizeof(uint32_t), st));
+    const uint32_t h = ix->img.hash_len;
+    if (max_len == 0 || max_len > stride_words * 16) max_len = stride_words * 16;
+    if (max_len > 255) max_len = 255;
+    cq::QueryArgs a{};
+    a.packed = d_packed;
+    a.lens = d_lens;
+    a.n_reads = n_reads;
+    a.stride_words = stride_words;
+    a.wmax = max_len >= h ? max_len - h + 1 : 1;
+    a.n_genomes = n_genomes;
+    a.mode = mode;
+    a.counters = d_counters;
+    a.rcount = (mode == CQ_MODE_P) ? d_rcount : nullptr;
+    a.ovf_list = ix->d_ovf_list;
+    a.ovf_count = ix->d_ovf_count;
+    a.ovf_cap = (uint32_t)ix->ovf_cap;
+    a.pair_keys = ix->d_pair_keys;
+    a.pair_cnts = ix->d_pair_cnts;
+    a.pair_cap = kPairCap;
+    CQ_HIP(cq::launch_classify(ix->dev, a, ix->n_cus, st, ix->ev0, ix->ev1));
+    ix->ev_valid = true;
+    return CQ_OK;
+}
+
+int cq_last_kernel_ms(cq_index *ix, float *ms)
+{
+    if (!ix || !ms) return fail(CQ_ERR_ARG, "cq_last_kernel_ms: NULL argument");
+    if (!ix->ev_valid) return fail(CQ_ERR_ARG, "cq_last_kernel_ms: no kernel has been launched on this handle");
+    CQ_HIP(hipEventSynchronize(ix->ev1));
+    CQ_HIP(hipEventElapsedTime(ms, ix->ev0, ix->ev1));
+    return CQ_OK;
+}
+
+int cq_pairs_fetch(cq_index *ix, uint32_t *pair_a, uint32_t *pair_b, uint64_t *pair_cnt,
+                   uint64_t pair_cap, uint64_t *n_pairs)
+{
+    if (!ix || !n_pairs) return fail(CQ_ERR_ARG, "cq_pairs_fetch: NULL argument");
+    if (ix->device < 0) return fail(CQ_ERR_NO_DEVICE, "index was loaded host-only");
+    CQ_HIP(hipSetDevice(ix->device));
+    CQ_HIP(hipDeviceSynchronize());
+    std::vector<uint64_t> k(kPairCap), c(kPairCap);
+    CQ_HIP(hipMemcpy(k.data(), ix->d_pair_keys, (size_t)kPairCap * 8, hipMemcpyDeviceToHost));
+    CQ_HIP(hipMemcpy(c.data(), ix->d_pair_cnts, (size_t)kPairCap * 8, hipMemcpyDeviceToHost));
+    CQ_HIP(hipMemset(ix->d_pair_keys, 0xFF, (size_t)kPairCap * 8));
+    CQ_HIP(hipMemset(ix->d_pair_cnts, 0, (size_t)kPairCap * 8));
+    uint64_t n = 0;
+    for (uint32_t i = 0; i < kPairCap; i++) {
+        if (k[i] == CQ_EMPTY_KEY) continue;
+        if (n < pair_cap && pair_a && pair_b && pair_cnt) {
+            pair_a[n] = (uint32_t)(k[i] >> 32);
+            pair_b[n] = (uint32_t)k[i];
+            pair_cnt[n] = c[i];
+        }
+        n++;
+    }
+    *n_pairs = n;
+    if (n > pair_cap) return fail(CQ_ERR_LIMIT, "more distinct pairs than pair_cap");
+    return CQ_OK;
+}
+
+int cq_query(cq_index *ix, int mode, const uint8_t *bases, const uint64_t *offsets,
+             uint64_t n_reads, uint32_t n_genomes, cq_counts *out)
+{
+    if (!ix || !out || !offsets) return fail(CQ_ERR_ARG, "cq_query: NULL argument");
+    if (!out->cnt_u || !out->cnt_d) return fail(CQ_ERR_ARG, "cq_query: cnt_u / cnt_d must be provided");
+    if (mode == CQ_MODE_P && (!out->rcount_u || !out->rcount_d) &&
+        (ix->img.n_leaves[0] + ix->img.n_leaves[1]) != 0 && !(out->rcount_u == nullptr && ix->img.n_leaves[0] == 0) &&
+        !(out->rcount_d == nullptr && ix->img.n_leaves[1] == 0))
+        return fail(CQ_ERR_ARG, "cq_query: rcount_u / rcount_d are mandatory in CQ_MODE_P (the ILP reads them)");
+    if (ix->device < 0) return fail(CQ_ERR_NO_DEVICE, "index was loaded host-only (CQ_DEVICE_NONE); no CPU classify path exists");
+    if (ix->img.max_refid > n_genomes)
+        return fail(CQ_ERR_RANGE, "index holds refID " + std::to_string(ix->img.max_refid) + " > n_genomes");
+    CQ_HIP(hipSetDevice(ix->device));
+
+    const uint64_t G1 = (uint64_t)n_genomes + 1, cw = cq_counter_words(n_genomes);
+    const uint64_t nl = ix->img.n_leaves[0] + ix->img.n_leaves[1];
+    uint64_t *d_ctr = nullptr;
+    uint32_t *d_rc = nullptr;
+    CQ_HIP(hipMalloc((void **)&d_ctr, cw * 8));
+    CQ_HIP(hipMemset(d_ctr, 0, cw * 8));
+    if (mode == CQ_MODE_P && nl) {
+        CQ_HIP(hipMalloc((void **)&d_rc, nl * 4));
+        CQ_HIP(hipMemset(d_rc, 0, nl * 4));
+    }
+    // One call = one FASTQ; long inputs go through in chunks so the staging buffers stay bounded.
+    const uint64_t kChunk = 1ull << 24;
+    uint64_t skipped_host = 0;
+    int rc = CQ_OK;
+    std::vector<uint32_t> packed;
+    std::vector<uint8_t> lens;
+    uint32_t *d_packed = nullptr;
+    uint8_t *d_lens = nullptr;
+    uint64_t d_cap_reads = 0;
+    uint32_t d_cap_sw = 0;
+    for (uint64_t c0 = 0; c0 < n_reads && rc == CQ_OK; c0 += kChunk) {
+        const uint64_t n = std::min(kChunk, n_reads - c0);
+        uint64_t max_len = 0;
+        for (uint64_t r = c0; r < c0 + n; r++) {
+            uint64_t l = offsets[r + 1] - offsets[r];
+            if (l <= 255 && l > max_len) max_len = l;
+        }
+        const uint32_t sw = cq_pack_stride_words((uint32_t)max_len);
+        packed.resize(n * sw);
+        lens.resize(n);
+        uint64_t sk = 0;
+        rc = cq_pack_reads(bases, offsets + c0, n, ix->img.hash_len, sw, packed.data(), lens.data(), &sk);
+        if (rc != CQ_OK) { fail(rc, "cq_pack_reads failed"); break; }
+        skipped_host += sk;
+        if (d_cap_reads < n || d_cap_sw < sw) {
+            if (d_packed) (void)hipFree(d_packed);
+            if (d_lens) (void)hipFree(d_lens);
+            d_packed = nullptr; d_lens = nullptr;
+            if (hipMalloc((void **)&d_packed, n * sw * 4) != hipSuccess || hipMalloc((void **)&d_lens, n) != hipSuccess) {
+                rc = fail(CQ_ERR_HIP, "hipMalloc of the read staging buffers failed");
+                break;
+            }
+            d_cap_reads = n; d_cap_sw = sw;
+        }
+        if (hipMemcpy(d_packed, packed.data(), n * sw * 4, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(d_lens, lens.data(), n, hipMemcpyHostToDevice) != hipSuccess) {
+            rc = fail(CQ_ERR_HIP, "hipMemcpy of reads to the device failed");
+            break;
+        }
+        rc = cq_query_device(ix, mode, d_packed, d_lens, n, sw, (uint32_t)max_len, n_genomes, d_ctr, d_rc, nullptr);
+        if (rc == CQ_OK && hipDeviceSynchronize() != hipSuccess) rc = fail(CQ_ERR_HIP, "classify kernel failed");
+    }
+    std::vector<uint64_t> ctr(cw, 0);
+    if (rc == CQ_OK && hipMemcpy(ctr.data(), d_ctr, cw * 8, hipMemcpyDeviceToHost) != hipSuccess)
+        rc = fail(CQ_ERR_HIP, "hipMemcpy of counters failed");
+    if (rc == CQ_OK && d_rc) {
+        if (out->rcount_u && ix->img.n_leaves[0] &&
+            hipMemcpy(out->rcount_u, d_rc, ix->img.n_leaves[0] * 4, hipMemcpyDeviceToHost) != hipSuccess)
+            rc = fail(CQ_ERR_HIP, "hipMemcpy of rcount_u failed");
+        if (rc == CQ_OK && out->rcount_d && ix->img.n_leaves[1] &&
+            hipMemcpy(out->rcount_d, d_rc + ix->img.n_leaves[0], ix->img.n_leaves[1] * 4, hipMemcpyDeviceToHost) != hipSuccess)
+            rc = fail(CQ_ERR_HIP, "hipMemcpy of rcount_d failed");
+    }
+    if (d_packed) (void)hipFree(d_packed);
+    if (d_lens) (void)hipFree(d_lens);
+    if (d_ctr) (void)hipFree(d_ctr);
+    if (d_rc) (void)hipFree(d_rc);
+    if (rc != CQ_OK) return rc;
+
+    memcpy(out->cnt_u, ctr.data(), G1 * 8);
+    memcpy(out->cnt_d, ctr.data() + G1, G1 * 8);
+    out->nundet = ctr[CQ_CTR_NUNDET(n_genomes)];
+    out->nconf = ctr[CQ_CTR_NCONF(n_genomes)];
+    out->nskipped = ctr[CQ_CTR_NSKIP(n_genomes)];
+    (void)skipped_host;  // == nskipped: the kernel counts rows whose length was zeroed by the packer
+    out->n_pairs = 0;
+    if (mode == CQ_MODE_SC) {
+        if (ctr[CQ_CTR_FLAGS(n_genomes)] & 1ull) return fail(CQ_ERR_LIMIT, "device pair table full");
+        uint64_t np = 0;
+        rc = cq_pairs_fetch(ix, out->pair_a, out->pair_b, out->pair_cnt, out->pair_cap, &np);
+        out->n_pairs = np;
+        if (rc != CQ_OK) return rc;
+    }
+    return CQ_OK;
+}
+
+}  // extern "C"

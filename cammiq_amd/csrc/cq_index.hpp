@@ -1,0 +1,65 @@
+// cq_index.hpp -- internal host-side structures of libcammiq_hip.so.
+//
+// Data flow (all new code; the reference's counterpart is the pointer trie + robin_hood map
+// built by Hash::loadIdx64_p, /root/reference/src/hashtrie.cpp:425-507):
+//
+//   .bin1/.bin2 + .aux  --cq_decode_table-->  DecodedTable (leaves in file order, one root
+//                                             code per bucket, 16-byte array-trie nodes)
+//   2 x DecodedTable    --cq_build_image--->  FlatImage   (merged u+d open-addressing table
+//                                             of 64-byte buckets, linked trie, leaf refIDs)
+//   FlatImage           --upload----------->  HBM
+#ifndef CQ_INDEX_HPP_
+#define CQ_INDEX_HPP_
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/cammiq_hip.h"
+#include "cq_device.h"
+
+namespace cq {
+
+// A trie reference ("code"): 0 = absent, CQ_LEAF_BIT|leaf id = leaf, otherwise node index (>=1).
+struct Node { uint32_t child[4]; };  // A,C,G,T -- one 16-byte load per level on the GPU
+
+struct DecodedTable {
+    uint32_t hash_len = 0;
+    uint32_t doubly = 0;
+    uint64_t n_file_buckets = 0;
+    std::vector<cq_leaf> leaves;        // decode order (== map_sp fill order)
+    std::vector<uint64_t> bucket_key;   // hv of each bucket, file order
+    std::vector<uint32_t> bucket_code;  // root code of each bucket (table-local ids)
+    std::vector<Node> nodes;            // nodes[0] is a reserved dummy
+};
+
+// Device-ready image.  Everything is plain arrays so upload is a handful of memcpys.
+struct FlatImage {
+    uint32_t hash_len = 0;
+    uint64_t n_leaves[2] = {0, 0};
+    uint64_t n_buckets = 0;       // hash range: a key's home bucket is in [0, n_buckets)
+    uint64_t n_buckets_alloc = 0; // n_buckets + spill tail
+    uint64_t n_keys = 0;
+    uint64_t n_overflowed = 0;
+    uint32_t max_chain = 1;
+    uint32_t max_refid = 0;
+    std::vector<cq_slot> slots;   // 4 per bucket
+    std::vector<Node> nodes;      // linked: d-table indices/leaf ids already offset
+    std::vector<uint32_t> leaf_r1, leaf_r2;  // global leaf id -> refIDs (u leaves first)
+};
+
+// Decode one index file pair.  Returns CQ_OK or a negative cq_status and fills err.
+int decode_table(const std::string &path, DecodedTable &out, std::string &err);
+void make_empty_table(uint32_t hash_len, DecodedTable &out);
+
+// Merge + lay out.  load_factor = average keys per 4-slot bucket (default 1.5).
+int build_image(const DecodedTable &u, const DecodedTable &d, double keys_per_bucket,
+                FlatImage &img, std::string &err);
+
+// Host mirror of the device lookup (used by tests of the layout through the C ABI and by
+// build_image's self-check).  Returns the slot values for `key` (0,0 when absent).
+void image_lookup(const FlatImage &img, uint64_t key, uint32_t &val_u, uint32_t &val_d,
+                  uint32_t *chain_len = nullptr);
+
+}  // namespace cq
+#endif

@@ -1,0 +1,44 @@
+// cq_kernels.h -- launch interface between the C ABI (cq_api.cpp) and the HIP kernels.
+#ifndef CQ_KERNELS_H_
+#define CQ_KERNELS_H_
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/cammiq_hip.h"
+
+namespace cq {
+
+// Device view of the index (all pointers into HBM).
+struct DevIndex {
+    const uint4 *slots;      // n_buckets_alloc * 4 slots of 16 B (cq_slot)
+    const uint4 *nodes;      // array trie, 16 B per node
+    const uint2 *leaf_rids;  // global leaf id -> (refID1, refID2)
+    uint32_t n_buckets;      // hash range
+    uint32_t hash_len;
+};
+
+struct QueryArgs {
+    const uint32_t *packed;  // n_reads rows of stride_words uint32
+    const uint8_t *lens;
+    uint64_t n_reads;
+    uint32_t stride_words;
+    uint32_t wmax;           // max windows per read in this batch: max_len - h + 1
+    uint32_t n_genomes;
+    int mode;
+    uint64_t *counters;      // cq_counter_words(n_genomes)
+    uint32_t *rcount;        // may be null
+    uint32_t *ovf_list;      // reads whose hit list overflowed the fast path
+    uint32_t *ovf_count;
+    uint32_t ovf_cap;
+    uint32_t use_lds_hist;
+    uint64_t *pair_keys;     // SC mode pair map (power-of-two capacity)
+    uint64_t *pair_cnts;
+    uint32_t pair_cap;
+};
+
+hipError_t launch_classify(const DevIndex &ix, QueryArgs a, int n_cus, hipStream_t stream,
+                           hipEvent_t ev_start, hipEvent_t ev_stop);
+
+}  // namespace cq
+#endif

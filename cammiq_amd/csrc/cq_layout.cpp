@@ -1,0 +1,210 @@
+// cq_layout.cpp -- turn two decoded tables into the flat HBM image.
+//
+// Replaces the reference's in-memory index (robin_hood::unordered_map<uint64_t, trieNode*>
+// + heap pointer trie, /root/reference/src/hashtrie.hpp:8-13,49; hashtrie.cpp:8-13) by:
+//
+//   * ONE merged open-addressing table for ht_u and ht_d.  A slot is 16 B
+//     {key = hv, val_u, val_d}; 4 slots form a 64-byte bucket = one HBM access, so the two
+//     find64_p calls the reference makes per window (query.cpp:487-492) cost one probe.
+//     Collisions stay inside the home bucket; a full bucket sets an overflow bit and spills
+//     to the next bucket(s).  A lookup that does not see the overflow bit stops after one
+//     bucket -- which is what >95 % of the (miss-dominated) probes do.
+//   * a linked array trie (16-byte nodes, 4 child codes) for keys longer than h.
+//   * leaf refIDs as two flat uint32 arrays indexed by global leaf id (u leaves first).
+//
+// Placement is a deterministic sort + linear sweep (no hashing races, sequential writes):
+// keys sorted by home bucket are dealt into buckets in order; what does not fit is carried
+// to the next bucket, whose predecessor gets the overflow bit.  The sweep never wraps: the
+// table has CQ_SPILL_TAIL buckets past the hash range.
+#include <algorithm>
+#include <atomic>
+#include <cstring>
+#include <thread>
+
+#include "cq_index.hpp"
+
+namespace cq {
+
+namespace {
+
+struct Entry {
+    uint32_t home;
+    uint32_t seq;      // file order inside (table, file): later duplicate wins (map64[b] = root)
+    uint64_t key;
+    uint32_t val_u, val_d;
+};
+
+inline bool entry_less(const Entry &a, const Entry &b)
+{
+    if (a.home != b.home) return a.home < b.home;
+    if (a.key != b.key) return a.key < b.key;
+    return a.seq < b.seq;
+}
+
+// Sort by (home, key, seq).  Parallel: partition by the top bits of `home`, sort the parts.
+void sort_entries(std::vector<Entry> &e, uint32_t n_buckets)
+{
+    const size_t n = e.size();
+    unsigned hw = std::thread::hardware_concurrency();
+    unsigned nt = std::min(hw ? hw : 1u, 32u);
+    if (n < (1u << 18) || nt < 2) { std::sort(e.begin(), e.end(), entry_less); return; }
+    const unsigned parts = 256;
+    std::vector<size_t> cnt(parts + 1, 0);
+    auto part_of = [&](uint32_t home) { return (unsigned)(((uint64_t)home * parts) / n_buckets); };
+    for (size_t i = 0; i < n; i++) cnt[part_of(e[i].home) + 1]++;
+    for (unsigned p = 0; p < parts; p++) cnt[p + 1] += cnt[p];
+    std::vector<Entry> tmp(n);
+    {
+        std::vector<size_t> cur(cnt.begin(), cnt.end() - 1);
+        for (size_t i = 0; i < n; i++) tmp[cur[part_of(e[i].home)]++] = e[i];
+    }
+    e.swap(tmp);
+    std::vector<std::thread> th;
+    std::atomic<unsigned> next{0};
+    for (unsigned t = 0; t < nt; t++)
+        th.emplace_back([&] {
+            for (;;) {
+                unsigned p = next.fetch_add(1);
+                if (p >= parts) break;
+                std::sort(e.begin() + cnt[p], e.begin() + cnt[p + 1], entry_less);
+            }
+        });
+    for (auto &x : th) x.join();
+}
+
+}  // namespace
+
+int build_image(const DecodedTable &u, const DecodedTable &d, double keys_per_bucket,
+                FlatImage &img, std::string &err)
+{
+    img = FlatImage();
+    if (u.hash_len != d.hash_len) { err = "hash lengths of the two index files differ"; return CQ_ERR_HASHLEN; }
+    img.hash_len = u.hash_len;
+    const uint64_t nu = u.leaves.size(), nd = d.leaves.size();
+    if (nu + nd >= 0x7FFFFFFFull) { err = "more than 2^31-1 leaves in total"; return CQ_ERR_LIMIT; }
+    img.n_leaves[0] = nu;
+    img.n_leaves[1] = nd;
+
+    // ---- link the two tries into one node array; give leaves global ids (u first)
+    const uint64_t nnu = u.nodes.size() - 1, nnd = d.nodes.size() - 1;  // real nodes (index 0 = dummy)
+    if (nnu + nnd + 1 >= 0x7FFFFFFFull) { err = "more than 2^31-1 trie nodes in total"; return CQ_ERR_LIMIT; }
+    img.nodes.resize(1 + nnu + nnd);
+    img.nodes[0] = Node{{0, 0, 0, 0}};
+    for (uint64_t i = 1; i <= nnu; i++) img.nodes[i] = u.nodes[i];  // u codes are already global
+    const uint32_t node_off = (uint32_t)nnu, leaf_off = (uint32_t)nu;
+    auto relink_d = [&](uint32_t code) -> uint32_t {
+        if (code == 0) return 0;
+        if (code & CQ_LEAF_BIT) return CQ_LEAF_BIT | ((code & ~CQ_LEAF_BIT) + leaf_off);
+        return code + node_off;
+    };
+    for (uint64_t i = 1; i <= nnd; i++) {
+        Node n = d.nodes[i];
+        for (int c = 0; c < 4; c++) n.child[c] = relink_d(n.child[c]);
+        img.nodes[nnu + i] = n;
+    }
+
+    img.leaf_r1.resize(nu + nd);
+    img.leaf_r2.resize(nu + nd);
+    uint32_t maxr = 0;
+    for (uint64_t i = 0; i < nu; i++) {
+        img.leaf_r1[i] = u.leaves[i].refID1; img.leaf_r2[i] = u.leaves[i].refID2;
+        maxr = std::max(maxr, std::max(u.leaves[i].refID1, u.leaves[i].refID2));
+    }
+    for (uint64_t i = 0; i < nd; i++) {
+        img.leaf_r1[nu + i] = d.leaves[i].refID1; img.leaf_r2[nu + i] = d.leaves[i].refID2;
+        maxr = std::max(maxr, std::max(d.leaves[i].refID1, d.leaves[i].refID2));
+    }
+    img.max_refid = maxr;
+
+    // ---- entries of both tables, sorted by (home bucket, key, file order)
+    const uint64_t nb_u = u.bucket_key.size(), nb_d = d.bucket_key.size();
+    if (keys_per_bucket <= 0.1) keys_per_bucket = 1.5;
+    uint64_t nbk = (uint64_t)((double)(nb_u + nb_d) / keys_per_bucket) + 1;
+    if (nbk < 16) nbk = 16;
+    if (nbk + CQ_SPILL_TAIL >= 0xFFFFFFFFull) { err = "table would exceed 2^32 buckets"; return CQ_ERR_LIMIT; }
+    img.n_buckets = nbk;
+    const uint32_t n_buckets = (uint32_t)nbk;
+
+    std::vector<Entry> ent;
+    ent.reserve(nb_u + nb_d);
+    for (uint64_t i = 0; i < nb_u; i++)
+        ent.push_back(Entry{cq_home_bucket(u.bucket_key[i], n_buckets), (uint32_t)i, u.bucket_key[i], u.bucket_code[i], 0});
+    for (uint64_t i = 0; i < nb_d; i++)
+        ent.push_back(Entry{cq_home_bucket(d.bucket_key[i], n_buckets), (uint32_t)i, d.bucket_key[i], 0, relink_d(d.bucket_code[i])});
+    sort_entries(ent, n_buckets);
+
+    // ---- merge duplicates (same key in both tables, or repeated within one file: the later
+    //      bucket wins, as map64[bucket] = root overwrites -- hashtrie.cpp:500)
+    size_t w = 0;
+    for (size_t i = 0; i < ent.size();) {
+        Entry m = ent[i];
+        size_t j = i + 1;
+        while (j < ent.size() && ent[j].key == m.key) j++;
+        // per table, the entry with the highest file position wins
+        uint32_t su = 0, sd = 0; bool hu = false, hd = false;
+        for (size_t k = i; k < j; k++) {
+            if (ent[k].val_u && (!hu || ent[k].seq >= su)) { m.val_u = ent[k].val_u; su = ent[k].seq; hu = true; }
+            if (ent[k].val_d && (!hd || ent[k].seq >= sd)) { m.val_d = ent[k].val_d; sd = ent[k].seq; hd = true; }
+        }
+        ent[w++] = m;
+        i = j;
+    }
+    ent.resize(w);
+    img.n_keys = w;
+
+    // ---- linear sweep placement
+    img.n_buckets_alloc = nbk + CQ_SPILL_TAIL;
+    img.slots.assign(img.n_buckets_alloc * CQ_SLOTS_PER_BUCKET, cq_slot{CQ_EMPTY_KEY, 0, 0});
+    size_t next = 0;         // next entry not yet pulled into the carry
+    size_t carry_lo = 0;     // entries [carry_lo, next) are waiting for a slot, oldest first
+    uint64_t overflowed = 0;
+    for (uint64_t b = 0; b < img.n_buckets_alloc; b++) {
+        while (next < w && ent[next].home <= b) next++;
+        size_t avail = next - carry_lo;
+        if (avail == 0) {
+            if (next >= w) break;
+            continue;
+        }
+        size_t take = std::min<size_t>(avail, CQ_SLOTS_PER_BUCKET);
+        cq_slot *s = &img.slots[b * CQ_SLOTS_PER_BUCKET];
+        for (size_t k = 0; k < take; k++) {
+            const Entry &e = ent[carry_lo + k];
+            s[k].key = e.key; s[k].val_u = e.val_u; s[k].val_d = e.val_d;
+            uint32_t chain = (uint32_t)(b - e.home) + 1;
+            if (chain > img.max_chain) img.max_chain = chain;
+        }
+        carry_lo += take;
+        if (carry_lo < next) {  // something is still waiting: this bucket is full and spilled
+            s[0].key |= CQ_OVERFLOW_BIT;
+            overflowed++;
+        }
+    }
+    if (carry_lo < w) { err = "spill tail exhausted while laying out the table"; return CQ_ERR_LIMIT; }
+    img.n_overflowed = overflowed;
+    return CQ_OK;
+}
+
+void image_lookup(const FlatImage &img, uint64_t key, uint32_t &val_u, uint32_t &val_d, uint32_t *chain_len)
+{
+    val_u = val_d = 0;
+    uint64_t b = cq_home_bucket(key, (uint32_t)img.n_buckets);
+    uint32_t chain = 0;
+    for (;;) {
+        const cq_slot *s = &img.slots[b * CQ_SLOTS_PER_BUCKET];
+        chain++;
+        for (int k = 0; k < CQ_SLOTS_PER_BUCKET; k++) {
+            uint64_t sk = (k == 0) ? (s[k].key & ~CQ_OVERFLOW_BIT) : s[k].key;
+            if (s[k].key != CQ_EMPTY_KEY && sk == key) {
+                val_u = s[k].val_u; val_d = s[k].val_d;
+                if (chain_len) *chain_len = chain;
+                return;
+            }
+        }
+        bool ovf = (s[0].key != CQ_EMPTY_KEY) && (s[0].key & CQ_OVERFLOW_BIT);
+        if (!ovf || b + 1 >= img.n_buckets_alloc) break;
+        b++;
+    }
+    if (chain_len) *chain_len = chain;
+}
+
+}  // namespace cq

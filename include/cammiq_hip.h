@@ -1,0 +1,188 @@
+/*
+ * cammiq_hip.h -- C ABI of libcammiq_hip.so, the MI355X (gfx950) engine for CAMMiQ's
+ * read-classification hot path.
+ *
+ * The reference (mounted at /root/reference; citations relative to its src/) has no
+ * plugin or FFI seam: the path is two C++ member functions that mutate FqReader state,
+ *
+ *     void FqReader::query64_p  (size_t file_idx)      query.hpp:113, query.cpp:458-648
+ *     void FqReader::query64mt_p(size_t file_idx)      query.hpp:114, query.cpp:650-889
+ *     void FqReader::query64_sc (size_t file_idx)      query.hpp:115, query.cpp:891-1080
+ *
+ * called from queryFastq_p (query.cpp:247-250,286-289) / queryFastq_sc (:319,356), on top
+ * of Hash::loadIdx64_p (hashtrie.cpp:486-507) and Hash::find64_p (:350-369).  This header
+ * is the boundary a maintainer binds instead (INTEGRATION.md shows the ~40-line patch):
+ * plain pointers and sizes, no C++ or torch types, caller owns every in/out array, the
+ * library owns the index and its device buffers behind an opaque handle.
+ *
+ * Every function returns CQ_OK (0) or a negative cq_status; the text of the last error
+ * on the calling thread is available from cq_last_error().  The library never aborts and
+ * has NO CPU fallback for the classify step: without a usable HIP device cq_query*
+ * fail with CQ_ERR_NO_DEVICE.
+ */
+#ifndef CAMMIQ_HIP_H_
+#define CAMMIQ_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CQ_ABI_VERSION 1
+
+typedef enum cq_status {
+    CQ_OK = 0,
+    CQ_ERR_ARG = -1,       /* NULL / out-of-range argument */
+    CQ_ERR_IO = -2,        /* cannot open/read a file (reference: abort(), binaryio.cpp:190-197) */
+    CQ_ERR_FORMAT = -3,    /* malformed .binN/.aux (reference: assert, hashtrie.cpp:446,492) */
+    CQ_ERR_HASHLEN = -4,   /* hash_len_u != hash_len_d (reference: assert, query.cpp:460) */
+    CQ_ERR_RANGE = -5,     /* a refID exceeds n_genomes (reference: genomes[rid] out of bounds) */
+    CQ_ERR_NO_DEVICE = -6, /* no HIP device / handle was loaded host-only */
+    CQ_ERR_HIP = -7,       /* a HIP runtime call failed */
+    CQ_ERR_NOMEM = -8,
+    CQ_ERR_LIMIT = -9      /* more than 2^31-1 leaves / nodes, key longer than 255, pair table full */
+} cq_status;
+
+/* Which classify routine is restated. */
+#define CQ_MODE_P 0  /* query64_p / query64mt_p: counts + per-leaf rcount            */
+#define CQ_MODE_SC 1 /* query64_sc: no rcount, pair counts, |P|>=2&|I|=1 bumps u too */
+
+#define CQ_TABLE_U 0 /* ht_u  (index_u.bin1) */
+#define CQ_TABLE_D 1 /* ht_d  (index_d.bin2) */
+
+#define CQ_DEVICE_NONE (-1) /* cq_index_load: decode + lay out on the host only (inspection) */
+
+typedef struct cq_index cq_index; /* opaque: replaces FqReader::ht_u / ht_d (query.hpp:57-58) */
+
+/* One decoded leaf = pleafNode minus rcount (hashtrie.hpp:37-47).  16 bytes. */
+typedef struct cq_leaf {
+    uint32_t refID1;
+    uint32_t refID2;  /* 0 for a unique marker */
+    uint16_t ucount1;
+    uint16_t ucount2;
+    uint8_t depth;    /* total key length = hash_len + trie depth (hashtrie.cpp:442,470) */
+    uint8_t pad_[3];
+} cq_leaf;
+
+typedef struct cq_index_info {
+    uint32_t abi_version;
+    uint32_t hash_len;         /* h, shared by both tables */
+    uint32_t max_refid;        /* largest refID in any leaf */
+    int32_t device;            /* HIP ordinal or CQ_DEVICE_NONE */
+    uint32_t doubly_flag[2];   /* header bit of each file (hashtrie.cpp:489) */
+    uint64_t n_leaves[2];      /* Hash::leaf_cnt per table */
+    uint64_t n_file_buckets[2];/* buckets decoded per file (== map64.size() unless duplicated) */
+    uint64_t n_trie_nodes;     /* internal trie nodes, both tables */
+    uint64_t n_keys;           /* distinct h-mer prefixes over both tables (merged table) */
+    uint64_t n_table_buckets;  /* 64-byte buckets in the device table (incl. spill tail) */
+    uint64_t n_overflowed;     /* buckets whose overflow bit is set */
+    uint32_t max_chain;        /* longest bucket chain a lookup can walk */
+    uint32_t reserved_;
+    uint64_t device_bytes;     /* HBM held by this handle */
+} cq_index_info;
+
+/*
+ * Replaces FqReader::loadIdx_p -> Hash::loadIdx64_p (query.cpp:109-123, hashtrie.cpp:486-507).
+ * Reads path_u and path_u+".aux" (and the same for path_d) in the reference's on-disk format,
+ * unchanged.  path_d may be NULL or "": the doubly-unique table is then empty (what a
+ * --unique build leaves behind; the reference itself would abort on the missing file).
+ * device >= 0 uploads the flat table + trie to that GPU; CQ_DEVICE_NONE keeps it on the host.
+ */
+int cq_index_load(const char *path_u, const char *path_d, int device, cq_index **out);
+
+int cq_index_get_info(const cq_index *idx, cq_index_info *info);
+
+/*
+ * Leaves of one table in FILE DECODE ORDER -- the order Hash::map_sp is filled in
+ * (hashtrie.cpp:452-453,476), so the host can rebuild map_sp[g] exactly:
+ * for i in order: push i to map_sp[refID1] (and to map_sp[refID2] when refID2 != 0).
+ * out must hold info.n_leaves[table] entries.
+ */
+int cq_index_leaves(const cq_index *idx, int table, cq_leaf *out);
+
+/*
+ * Diagnostic: host-side lookup of one h-mer (2*hash_len-bit value, the reference's map64 key)
+ * in the merged table, following exactly the bucket chain the GPU follows.  code_u / code_d
+ * receive the bucket root in ht_u / ht_d: 0 absent, 0x80000000|global leaf id (u leaves
+ * first, then d leaves) or a trie node index.  chain = buckets read.  Not a classify path.
+ */
+int cq_index_probe(const cq_index *idx, uint64_t hv, uint32_t *code_u, uint32_t *code_d, uint32_t *chain);
+
+void cq_index_free(cq_index *idx);
+
+/* Outputs of one classify call == the FqReader state query64_* mutates. */
+typedef struct cq_counts {
+    uint64_t *cnt_u;     /* [n_genomes+1]  Genome::read_cnts_u (query.hpp:15), index 0 unused */
+    uint64_t *cnt_d;     /* [n_genomes+1]  Genome::read_cnts_d (query.hpp:16) */
+    uint32_t *rcount_u;  /* [n_leaves[U]]  pleafNode::rcount, decode order; may be NULL in SC mode */
+    uint32_t *rcount_d;  /* [n_leaves[D]] */
+    uint64_t nundet;     /* FqReader::nundet (query.hpp:43) */
+    uint64_t nconf;      /* FqReader::nconf  (query.hpp:40) */
+    uint64_t nskipped;   /* reads outside the parity domain (len < h, len > 255, non-ACGT byte):
+                            not classified, not counted anywhere else.  Reference: UB. */
+    /* CQ_MODE_SC only: FqReader::read_cnts_b (query.hpp:49) as triples, any order. */
+    uint32_t *pair_a;    /* [pair_cap] smaller refID */
+    uint32_t *pair_b;    /* [pair_cap] larger refID  */
+    uint64_t *pair_cnt;  /* [pair_cap] */
+    uint64_t pair_cap;
+    uint64_t n_pairs;    /* out: distinct pairs (CQ_ERR_LIMIT if > pair_cap) */
+} cq_counts;
+
+/*
+ * Replaces one call of query64_p / query64mt_p / query64_sc on reads that sit in host
+ * memory as ASCII, exactly as FqReader::readFastq leaves them (query.cpp:371-393):
+ * read r is bases[offsets[r] .. offsets[r+1]).  Packs to 2 bit, copies to the GPU,
+ * classifies, copies the counters back.  Counters are OVERWRITTEN (one call == one FASTQ
+ * after resetCounters, query.cpp:1820-1840).  Synchronous.
+ */
+int cq_query(cq_index *idx, int mode, const uint8_t *bases, const uint64_t *offsets,
+             uint64_t n_reads, uint32_t n_genomes, cq_counts *out);
+
+/* ---- packed / device-resident interface (multi-GPU hosts, benchmarks, pipelines) ---- */
+
+/* Words (uint32) per packed read for reads up to max_len bases; multiple of 4 (16-byte rows). */
+uint32_t cq_pack_stride_words(uint32_t max_len);
+
+/*
+ * ASCII -> 2-bit rows.  Base j of a read goes to word j/16, bits [31-2(j%16) : 30-2(j%16)]
+ * (A=0 C=1 G=2 T=3, either case -- FqReader::symbolIdx, query.cpp:1860-1873).
+ * lens[r] = read length, or 0 when the read is outside the parity domain (see nskipped).
+ * packed: n_reads*stride_words uint32; lens: n_reads uint8.  Host only, multi-threaded.
+ */
+int cq_pack_reads(const uint8_t *bases, const uint64_t *offsets, uint64_t n_reads,
+                  uint32_t hash_len, uint32_t stride_words, uint32_t *packed, uint8_t *lens,
+                  uint64_t *n_skipped);
+
+/* Number of uint64 in the device counter block for n_genomes: [cnt_u | cnt_d | nundet nconf nskipped flags]. */
+uint64_t cq_counter_words(uint32_t n_genomes);
+
+/*
+ * Classify reads that are already resident in HBM.  Asynchronous on `stream` (a hipStream_t,
+ * NULL = default stream).  ACCUMULATES into d_counters (cq_counter_words(n_genomes) uint64,
+ * layout above) and d_rcount (n_leaves[U]+n_leaves[D] uint32, U first; may be NULL in SC
+ * mode); the caller zeroes them, sums them across GPUs (RCCL) and copies them back.
+ * d_packed/d_lens as produced by cq_pack_reads; max_len = longest read in the batch (an upper
+ * bound is fine: it only sizes the lane grid; 0 = stride_words*16).  n_reads <= 2^31 per call.
+ * SC-mode pair counts accumulate inside the handle; fetch with cq_pairs_fetch.
+ */
+int cq_query_device(cq_index *idx, int mode, const uint32_t *d_packed, const uint8_t *d_lens,
+                    uint64_t n_reads, uint32_t stride_words, uint32_t max_len, uint32_t n_genomes,
+                    uint64_t *d_counters, uint32_t *d_rcount, void *stream);
+
+/* SC mode: copy out and clear the pair counters accumulated by cq_query_device. Synchronises. */
+int cq_pairs_fetch(cq_index *idx, uint32_t *pair_a, uint32_t *pair_b, uint64_t *pair_cnt,
+                   uint64_t pair_cap, uint64_t *n_pairs);
+
+/* Duration in ms of the main classify kernel of the most recent cq_query_device call on this
+ * handle (HIP events on the call's stream; synchronises on the stop event). */
+int cq_last_kernel_ms(cq_index *idx, float *ms);
+
+const char *cq_last_error(void);
+int cq_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CAMMIQ_HIP_H_ */
