@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""bench.py -- Mreads/s of the CAMMiQ classify hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path (what FqReader::query64mt_p does for one FASTQ,
+/root/reference/src/query.cpp:650-889) over one batch of synthetic reads that is already
+resident in HBM: reset counters, classify kernel(s), and for N > 1 the RCCL all-reduce of the
+count vectors.  Index load / layout and FASTQ parsing are outside the bracket, exactly like
+the reference's own `Time for query` line (query.cpp:459,645-647).
+
+Workload at N = 1 = BASELINE.json configs[1]: 500 synthetic bacterial-size genomes, --unique
+index (h = k = 26), 10 M x 100 bp reads.  N > 1 is weak scaling: the index is replicated and
+every rank classifies its own 10 M reads (configs[3] shape).  Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import shutil
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+METRIC = "Mreads/sec classified (100 bp, L=26); per-genome hit counts bit-exact"
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def algorithmic_bytes_per_read(rl: int, h: int, tables: int) -> int:
+    """B = ceil(rl/4) + 2*(rl-h+1)*T*16 (hits omitted -> lower bound)."""
+    return (rl + 3) // 4 + 2 * (rl - h + 1) * tables * 16
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--genomes", type=int, default=500)
+    ap.add_argument("--genome-len", type=int, default=3_450_000)
+    ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU per step")
+    ap.add_argument("--read-len", type=int, default=100)
+    ap.add_argument("--both", action="store_true", help="unique + doubly-unique index (configs[2] shape)")
+    ap.add_argument("--cpu-sample", type=int, default=200_000, help="reads timed through the CPU oracle (0 = skip)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N > 1 through torch.distributed.run (see the docstring)")
+        args.gpus = world
+
+    import torch
+    import cammiq_amd as cq
+    from cammiq_amd import bigsynth, dist as cqdist
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the classify path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as tdist
+        tdist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    h = k = 26
+    G = args.genomes
+    tables = 2 if args.both else 1
+    t_setup = time.time()
+    wdir = tempfile.mkdtemp(prefix=f"cammiq_bench_r{rank}_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    try:
+        w = bigsynth.World(seed=2, n_genomes=G, genome_len=args.genome_len, k=k, h=h, lmax=50,
+                           pair_share=0.3 if args.both else 0.0)
+        pu = os.path.join(wdir, "index_u.bin1")
+        pd = os.path.join(wdir, "index_d.bin2") if args.both else None
+        nu, nd = w.write_index(pu, pd)
+        t_gen = time.time() - t_setup
+        t0 = time.time()
+        ix = cq.Index(pu, pd, device=local_rank)
+        t_load = time.time() - t0
+        info = ix.info_dict()
+
+        n = args.reads
+        bases, offs = w.reads(seed=1000 + rank, n=n, length=args.read_len)
+        t0 = time.time()
+        packed, lens, skipped = cq.pack_reads(bases, offs, h)
+        t_pack = time.time() - t0
+        sw = packed.shape[1]
+        d_packed = torch.from_numpy(packed.view(np.int32)).cuda()
+        d_lens = torch.from_numpy(lens).cuda()
+        ctr = torch.zeros(ix.counter_words(G), dtype=torch.int64, device="cuda")
+        rc = torch.zeros(max(nu + nd, 1), dtype=torch.int32, device="cuda")
+        stream = torch.cuda.current_stream().cuda_stream
+
+        def step():
+            ctr.zero_()                       # resetCounters (query.cpp:1820-1840)
+            rc.zero_()
+            ix.query_device(cq.MODE_P, d_packed.data_ptr(), d_lens.data_ptr(), n, sw, args.read_len, G,
+                            ctr.data_ptr(), rc.data_ptr(), stream)
+            if world > 1:
+                cqdist.allreduce_counts(ctr, rc)
+
+        def fence():
+            if world > 1:
+                tdist.barrier()
+            torch.cuda.synchronize()
+
+        for _ in range(args.warmup):
+            step()
+        fence()
+        kms = []
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+            kms.append(ix.last_kernel_ms())   # HIP events on the launch stream, recorded inside the library
+        fence()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            tdist.all_reduce(tmax, op=tdist.ReduceOp.MAX)
+            dt = float(tmax.item())
+
+        # ---- sanity on the last step's counters: every read lands in exactly one outcome
+        c = ctr.cpu().numpy().astype(np.uint64)
+        tot_reads = n * world
+        nundet, nconf, nskip, nslow = (int(c[2 * (G + 1) + i]) for i in (0, 1, 2, 4))
+        cnt_u_sum = int(c[:G + 1].sum())
+        if not args.both:
+            assert cnt_u_sum + nundet + nconf + nskip == tot_reads, "conservation of reads violated"
+
+        result = None
+        if rank == 0:
+            value = tot_reads * args.steps / dt / 1e6
+            B = algorithmic_bytes_per_read(args.read_len, h, tables)
+            k_ms = float(np.mean(kms))
+            achieved = n * B / (k_ms * 1e-3) / 1e9
+            traffic = None
+            tp = os.path.join(ROOT, "profiles", "traffic.json")
+            if os.path.exists(tp):
+                try:
+                    traffic = json.load(open(tp)).get("hbm_bytes_per_launch")
+                except Exception:
+                    traffic = None
+            result = {
+                "metric": METRIC, "value": round(value, 3), "unit": "Mreads/s", "n_gpus": world,
+                "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64",
+                "data": "synthetic",
+                "config": {"workload": ("configs[2]-shape: " if args.both else "configs[1]: ") +
+                           f"{G} synthetic genomes x {args.genome_len} bp, "
+                           f"{'--both' if args.both else '--unique'} index h=k=26 ({nu}+{nd} leaves), "
+                           f"{n} x {args.read_len} bp reads per GPU per step (1% subst. errors, 10% off-database)",
+                           "reads_per_gpu": n, "read_len": args.read_len, "hash_len": h, "n_genomes": G,
+                           "leaves_u": nu, "leaves_d": nd, "table_GB": round(info["n_table_buckets"] * 64 / 1e9, 3),
+                           "index_device_GB": round(info["device_bytes"] / 1e9, 3),
+                           "parallelism": f"reads sharded x{world}, index replicated" +
+                                          (", RCCL all-reduce of counts + rcount per step" if world > 1 else "")},
+                "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                             "kernel": "classify_kernel<64,16,false>", "kernel_ms": round(k_ms, 4),
+                             "algorithmic_bytes_per_read": B},
+                "kernel_Mreads_s": round(n / (k_ms * 1e-3) / 1e6, 3),
+                "outcome": {"nundet": nundet, "nconf": nconf, "nskipped": nskip, "slow_path_reads": nslow,
+                            "cnt_u_sum": cnt_u_sum},
+                "setup_s": {"generate": round(t_gen, 2), "index_load_layout_upload": round(t_load, 2),
+                            "pack_reads": round(t_pack, 2)},
+            }
+
+        # ---- CPU baseline (rank 0, N = 1 only): the oracle, a restatement of query64mt_p
+        if rank == 0 and world == 1 and not args.no_cpu_baseline and args.cpu_sample > 0:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import oracle_lib
+            ns = min(args.cpu_sample, n)
+            cores = os.cpu_count() or 1
+            oi = oracle_lib.OracleIndex(pu, pd)
+            sb, so = bases[:ns * args.read_len], offs[:ns + 1]
+            t0 = time.perf_counter()
+            ref = oi.query(sb, so, G, mode=0, nthreads=cores)
+            tc = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            ns1 = max(ns // 8, 1)
+            oi.query(bases[:ns1 * args.read_len], offs[:ns1 + 1], G, mode=0, nthreads=1)
+            tc1 = time.perf_counter() - t0
+            # parity gate on the very same sample, through the product's host API
+            got = ix.query(sb, so, G)
+            parity = all(np.array_equal(got[kk], ref[kk]) for kk in ("cnt_u", "cnt_d", "rcount_u", "rcount_d")) \
+                and got["nundet"] == ref["nundet"] and got["nconf"] == ref["nconf"]
+            if not parity:
+                raise SystemExit("PARITY FAILURE: GPU counters differ from the CPU oracle on the bench sample")
+            result["cpu_baseline"] = {
+                "value": round(ns / tc / 1e6, 4), "unit": "Mreads/s", "cores": cores, "kind": "port",
+                "sample": f"first {ns} reads of the same batch, same index; OpenMP over reads with one global "
+                          f"critical section per update as query64mt_p (oracle/cammiq_oracle.c); "
+                          f"single-thread rate on {ns1} reads: {ns1 / tc1 / 1e6:.4f} Mreads/s",
+                "cpu_model": _cpu_model(), "seconds": round(tc + tc1, 2)}
+            result["parity_checked_reads"] = ns
+        if rank == 0:
+            print(json.dumps(result), flush=True)
+    finally:
+        shutil.rmtree(wdir, ignore_errors=True)
+        if world > 1:
+            tdist.destroy_process_group()
+
+
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+if __name__ == "__main__":
+    main()

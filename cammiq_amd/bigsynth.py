@@ -1,0 +1,69 @@
+"""ctypes wrapper of libcq_synth.so: benchmark-scale synthetic genomes / indices / reads
+(see csrc/cq_synth.cpp).  Not on the hot path."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class _Params(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("n_genomes", C.c_uint32), ("genome_len", C.c_uint32),
+                ("k", C.c_uint32), ("h", C.c_uint32), ("lmax", C.c_uint32), ("marker_every", C.c_uint32),
+                ("block", C.c_uint32), ("frac_deep", C.c_double), ("pair_share", C.c_double)]
+
+
+def _lib():
+    global _LIB
+    if _LIB is None:
+        L = C.CDLL(os.path.join(_HERE, "libcq_synth.so"))
+        L.cqs_create.restype = C.c_void_p
+        L.cqs_create.argtypes = [C.POINTER(_Params)]
+        L.cqs_free.argtypes = [C.c_void_p]
+        L.cqs_write_index.restype = C.c_int
+        L.cqs_write_index.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.cqs_make_reads.restype = C.c_int
+        L.cqs_make_reads.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_double, C.c_double, C.c_void_p]
+        _LIB = L
+    return _LIB
+
+
+class World:
+    """G random genomes (+ optional pairwise shared blocks), their marker index, their reads."""
+
+    def __init__(self, seed: int, n_genomes: int, genome_len: int, k: int = 26, h: int = 26, lmax: int = 50,
+                 marker_every: int = 69, frac_deep: float = 0.07, pair_share: float = 0.0, block: int = 2048):
+        self.p = _Params(seed, n_genomes, genome_len, k, h, lmax, marker_every, block, frac_deep, pair_share)
+        self.n_genomes = n_genomes
+        self._h = _lib().cqs_create(C.byref(self.p))
+
+    def write_index(self, path_u: str, path_d: str | None = None):
+        nu, nd = C.c_uint64(0), C.c_uint64(0)
+        rc = _lib().cqs_write_index(self._h, path_u.encode(), path_d.encode() if path_d else None,
+                                    C.byref(nu), C.byref(nd))
+        if rc != 0:
+            raise IOError(f"cannot write {path_u}")
+        return int(nu.value), int(nd.value)
+
+    def reads(self, seed: int, n: int, length: int = 100, err: float = 0.01, frac_random: float = 0.1):
+        """-> (bases uint8[n*length], offsets uint64[n+1])"""
+        bases = np.empty(n * length, np.uint8)
+        rc = _lib().cqs_make_reads(self._h, seed, n, length, err, frac_random, bases.ctypes.data_as(C.c_void_p))
+        if rc != 0:
+            raise ValueError("read length exceeds genome length")
+        return bases, np.arange(n + 1, dtype=np.uint64) * np.uint64(length)
+
+    def close(self):
+        if self._h:
+            _lib().cqs_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -126,49 +126,87 @@ def select_markers(genomes: Sequence[bytes], k: int, lmax: int, keep_every: int 
 
 # --------------------------------------------------------------------------- writer
 
-class _BitSink:
-    """BitWriter::writeBit (binaryio.cpp:11-30): MSB first, a byte is emitted when
-    its 8th bit arrives; a trailing partial byte is never written."""
+class _Sink:
+    """The two output streams of BitWriter (binaryio.cpp:11-123).
 
-    def __init__(self):
-        self.buf = bytearray()
+    .aux: writeBit is MSB first, a byte is emitted when its 8th bit arrives and a trailing
+    partial byte is never written.  .binN: big-endian 16/32/64-bit integers.
+    ``trace`` (optional list) records every call as (op, arg, value) with the op codes of
+    oracle/ref_binaryio_driver.cpp, so a test can replay it through the reference's own
+    BitWriter and demand byte-identical files.
+    """
+
+    def __init__(self, trace=None):
+        self.aux = bytearray()
+        self.ints = bytearray()
         self.cur = 0
         self.n = 0
+        self.trace = trace
 
-    def bit(self, b: int):
+    def _bit(self, b: int):
         self.cur = (self.cur << 1) | (b & 1)
         self.n += 1
         if self.n == 8:
-            self.buf.append(self.cur)
+            self.aux.append(self.cur)
             self.cur = 0
             self.n = 0
 
+    def bit(self, b: int):
+        if self.trace is not None:
+            self.trace.append((0, 0, b & 1))
+        self._bit(b)
+
     def bits(self, count: int, value: int):
+        if self.trace is not None:
+            self.trace.append((1, count, value))
         for i in range(count):
-            self.bit((value >> (count - 1 - i)) & 1)
+            self._bit((value >> (count - 1 - i)) & 1)
+
+    def u16(self, v: int):
+        if self.trace is not None:
+            self.trace.append((2, 0, v))
+        self.ints += v.to_bytes(2, "big")
+
+    def u32(self, v: int):
+        if self.trace is not None:
+            self.trace.append((3, 0, v))
+        self.ints += v.to_bytes(4, "big")
+
+    def u64(self, v: int):
+        if self.trace is not None:
+            self.trace.append((4, 0, v))
+        self.ints += v.to_bytes(8, "big")
+
+    def flush64(self):
+        """flush64 = flush64i (72 one-bits, binaryio.cpp:115-118) + flush64a (END64 then a
+        16-bit 0xFFFF, :120-123)."""
+        if self.trace is not None:
+            self.trace.append((5, 0, 0))
+        for _ in range(72):
+            self._bit(1)
+        self.ints += END64.to_bytes(8, "big") + (0xFFFF).to_bytes(2, "big")
 
 
-def _emit_trie(node, aux: _BitSink, ints: bytearray, doubly: bool):
+def _emit_trie(node, out: _Sink, doubly: bool):
     """encodeTrie / encodeTrie_d (hashtrie.cpp:599-623): '1', four children in A,C,G,T
     order ('0' when absent), then the leaf record if the node is a leaf."""
-    aux.bit(1)
+    out.bit(1)
     if isinstance(node, tuple):  # leaf record
         for _ in range(4):
-            aux.bit(0)
+            out.bit(0)
         if doubly:
             r1, r2, c1, c2 = node
-            ints += r1.to_bytes(4, "big") + r2.to_bytes(4, "big")
-            ints += c1.to_bytes(2, "big") + c2.to_bytes(2, "big")
+            out.u32(r1); out.u32(r2); out.u16(c1); out.u16(c2)
         else:
             r1, c1 = node
-            ints += r1.to_bytes(4, "big") + c1.to_bytes(2, "big")
+            out.u32(r1); out.u16(c1)
         return
     for c in range(4):
         ch = node.get(c)
         if ch is None:
-            aux.bit(0)
+            out.bit(0)
         else:
-            _emit_trie(ch, aux, ints, doubly)
+            _emit_trie(ch, out, doubly)
 
 
 def build_buckets(keys: Dict[bytes, tuple], h: int):
@@ -202,7 +240,7 @@ def build_buckets(keys: Dict[bytes, tuple], h: int):
 
 
 def write_index(path: str, keys: Dict[bytes, tuple], h: int, doubly: bool,
-                order_seed: int | None = 0) -> int:
+                order_seed: int | None = 0, trace=None) -> int:
     """Write ``path`` and ``path + '.aux'``.  Returns the number of leaves.
 
     Bucket order in the reference is robin_hood's iteration order, i.e. arbitrary
@@ -212,21 +250,18 @@ def write_index(path: str, keys: Dict[bytes, tuple], h: int, doubly: bool,
     order = list(buckets.keys())
     if order_seed is not None:
         random.Random(order_seed).shuffle(order)
-    aux = _BitSink()
-    ints = bytearray()
-    aux.bit(1 if doubly else 0)      # encodeIdx64[_d]: flag
-    aux.bits(7, 64)                  # option
-    aux.bits(8, h)                   # hash length
+    out = _Sink(trace)
+    out.bit(1 if doubly else 0)      # encodeIdx64[_d]: flag (hashtrie.cpp:644,681)
+    out.bits(7, 64)                  # option
+    out.bits(8, h)                   # hash length
     for hv in order:
-        ints += hv.to_bytes(8, "big")
-        _emit_trie(buckets[hv], aux, ints, doubly)
-    for _ in range(72):              # flush64i (binaryio.cpp:115-118)
-        aux.bit(1)
-    ints += END64.to_bytes(8, "big") + (0xFFFF).to_bytes(2, "big")  # flush64a :120-123
+        out.u64(hv)
+        _emit_trie(buckets[hv], out, doubly)
+    out.flush64()
     with open(path, "wb") as f:
-        f.write(bytes(ints))
+        f.write(bytes(out.ints))
     with open(path + ".aux", "wb") as f:
-        f.write(bytes(aux.buf))
+        f.write(bytes(out.aux))
     return len(keys)
 
 

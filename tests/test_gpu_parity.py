@@ -1,0 +1,210 @@
+"""Parity tests proper: the HIP path (through the C ABI) against the oracle, bit for bit.
+Run on the GPU box:  python -m pytest tests -m gpu -x -q"""
+import os
+
+import numpy as np
+import pytest
+
+import cammiq_amd as cq
+from cammiq_amd import synth
+import oracle_lib
+from util import assert_same, build_index, golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _both(pu, pd, reads, G, mode=0):
+    b, o = synth.concat_reads(reads)
+    got = cq.Index(pu, pd, device=0).query(b, o, G, mode=mode)
+    ref = oracle_lib.OracleIndex(pu, pd).query(b, o, G, mode=mode)
+    return got, ref
+
+
+@pytest.mark.parametrize("name", ["f_deep", "f_flat"])
+def test_golden_fixtures(name):
+    g = golden(name)
+    b, o = synth.concat_reads(g["reads"])
+    ix = cq.Index(g["pu"], g["pd"], device=0)
+    got = ix.query(b, o, g["G"])
+    assert_same(got, g["exp"]["p"], name)
+    assert got["nskipped"] == 0
+    sc = ix.query(b, o, g["G"], mode=cq.MODE_SC)
+    assert_same(sc, g["exp"]["sc"], name + " sc", rcount=False)
+    assert sorted([a, b_, c] for (a, b_), c in sc["pairs"].items()) == g["exp"]["sc"]["pairs"]
+    assert int(sc["rcount_u"].sum()) == 0
+    # a second call on the same handle overwrites, it does not accumulate
+    assert_same(ix.query(b, o, g["G"]), g["exp"]["p"], name + " again")
+
+
+def test_survey_fixtures():
+    """Indices written by the reference's build; numbers as recorded in SURVEY.md 8(c)."""
+    g = golden("survey_F1")
+    b, o = synth.concat_reads(g["reads"])
+    got = cq.Index(g["pu"], g["pd"], device=0).query(b, o, g["G"])
+    assert list(map(int, got["cnt_u"])) == g["exp"]["survey"]["cnt_u"]
+    assert got["nundet"] == g["exp"]["survey"]["nundet"]
+    g = golden("survey_F2")
+    b, o = synth.concat_reads(g["reads"])
+    got = cq.Index(g["pu"], g["pd"], device=0).query(b, o, g["G"])
+    s = g["exp"]["survey"]
+    assert got["nundet"] == s["nundet"] and got["nconf"] == s["nconf"]
+    assert int(got["rcount_u"].sum()) == s["sum_rcount_u"]
+    assert 2 * int(got["rcount_d"].sum()) == s["sum_rcount_d_over_map_sp"]
+    ref = oracle_lib.OracleIndex(g["pu"], g["pd"]).query(b, o, g["G"])
+    assert_same(got, ref, "survey_F2")
+
+
+@pytest.mark.parametrize("h,k,lmax", [(5, 12, 20), (12, 12, 12), (16, 20, 40), (31, 31, 45)])
+def test_random_indices_all_hash_lengths(tmp_path, h, k, lmax):
+    gen = synth.clade_genomes(100 + h, 2, 3, 2000, 0.04)
+    u, d = synth.select_markers(gen, k, lmax, keep_every=3, seed=h)
+    pu, pd = build_index(tmp_path, u, d, h)
+    reads = synth.simulate_reads(gen, 3000, (max(h, 20), 255), 0.02, h, frac_random=0.15, lower_frac=0.1)
+    for mode in (0, 1):
+        got, ref = _both(pu, pd, reads, len(gen), mode)
+        assert_same(got, ref, f"h={h} mode={mode}", rcount=(mode == 0))
+        assert got["pairs"] == ref["pairs"]
+
+
+def test_unique_only_index(tmp_path):
+    gen = synth.clade_genomes(5, 5, 1, 3000, 0.0)
+    u, _ = synth.select_markers(gen, 26, 26, keep_every=2, seed=3)
+    pu, _pd = build_index(tmp_path, u, {}, 26)
+    reads = synth.simulate_reads(gen, 5000, 100, 0.01, 2, frac_random=0.1)
+    got, ref = _both(pu, None, reads, len(gen))
+    assert_same(got, ref, "unique-only")
+    assert int(got["cnt_d"].sum()) == 0 and got["rcount_d"].size == 0
+
+
+def test_edge_reads(tmp_path):
+    """rl == h, rl == 255, mixed lengths, lower case, reads with no window at all."""
+    gen = synth.clade_genomes(9, 2, 2, 1500, 0.03)
+    u, d = synth.select_markers(gen, 20, 30, keep_every=1, seed=1)
+    pu, pd = build_index(tmp_path, u, d, 20)
+    g0 = gen[0]
+    reads = [g0[10:30], g0[10:30].lower(), synth.revcomp(g0[100:120]), g0[0:255], synth.revcomp(g0[300:555]),
+             g0[50:71], g0[400:431].lower(), b"ACGT" * 5, b"A" * 255, b"T" * 20]
+    reads += synth.simulate_reads(gen, 500, (20, 255), 0.0, 4)
+    got, ref = _both(pu, pd, reads, len(gen))
+    assert_same(got, ref, "edge")
+    assert int(got["cnt_u"].sum()) + int(got["cnt_d"].sum()) > 0
+
+
+def test_reads_outside_the_parity_domain_are_skipped(tmp_path):
+    gen = synth.clade_genomes(9, 2, 2, 1500, 0.03)
+    u, d = synth.select_markers(gen, 20, 30, keep_every=2, seed=1)
+    pu, pd = build_index(tmp_path, u, d, 20)
+    good = synth.simulate_reads(gen, 300, (20, 200), 0.01, 4)
+    bad = [b"ACGT", b"", gen[0][:50] + b"N" + gen[0][51:100], b"A" * 300, gen[1][:19]]
+    mixed = good[:100] + bad[:2] + good[100:200] + bad[2:] + good[200:]
+    b, o = synth.concat_reads(mixed)
+    got = cq.Index(pu, pd, device=0).query(b, o, len(gen))
+    bg, og = synth.concat_reads(good)
+    ref = oracle_lib.OracleIndex(pu, pd).query(bg, og, len(gen))
+    assert_same(got, ref, "skipped")
+    assert got["nskipped"] == len(bad)
+
+
+def test_empty_input(tmp_path):
+    pu, pd = build_index(tmp_path, {b"ACGTACG": (1, 1)}, {}, 6)
+    b, o = synth.concat_reads([])
+    got = cq.Index(pu, pd, device=0).query(b, o, 1)
+    assert got["nundet"] == 0 and got["nconf"] == 0 and int(got["cnt_u"].sum()) == 0
+
+
+def test_dense_markers_take_the_exact_slow_path(tmp_path):
+    """Every position a marker (keep_every=1, small k): far more than 16 hits per read, so the
+    fast kernel hands every read to the slow kernel.  Results must not change."""
+    gen = synth.clade_genomes(31, 1, 3, 1200, 0.05)
+    u, d = synth.select_markers(gen, 10, 16, keep_every=1, seed=0)
+    pu, pd = build_index(tmp_path, u, d, 8)
+    reads = synth.simulate_reads(gen, 700, (60, 255), 0.005, 3)
+    got, ref = _both(pu, pd, reads, len(gen))
+    assert_same(got, ref, "dense")
+    assert int(np.max(ref["rcount_u"])) > 0
+
+
+def test_every_decision_branch_on_gpu(tmp_path):
+    K = [b"AAAAAC", b"AAAACC", b"AAACCC", b"AACCCC", b"ACCCCC", b"CCCCCA", b"CCCCAA"]
+    u = {K[0]: (1, 1), K[1]: (2, 1), b"GGGGGGT": (3, 1)}
+    d = {K[2]: (1, 2, 1, 1), K[3]: (1, 3, 1, 1), K[4]: (2, 3, 1, 1), K[5]: (4, 5, 1, 1), K[6]: (6, 6, 1, 1)}
+    pu, pd = build_index(tmp_path, u, d, 6)
+    reads = [b"TTTTTTGTGTGT", b"GTGT" + K[0] + b"GT", K[0] + b"GT" + K[1], b"GT" + K[2] + b"GT",
+             K[0] + b"G" + K[2] + b"G" + K[3], K[0] + b"G" + K[4], K[2] + b"G" + K[3], K[2] + b"G" + K[5],
+             b"ACGGGGGGT", b"ACGGGGGG", b"GT" + K[6] + b"GT", synth.revcomp(b"GTGT" + K[0] + b"GT")]
+    for mode in (0, 1):
+        for r in reads:   # one read at a time: any wrong branch shows up by name
+            got, ref = _both(pu, pd, [r], 6, mode)
+            assert_same(got, ref, f"read {r!r} mode {mode}", rcount=(mode == 0))
+            assert got["pairs"] == ref["pairs"]
+        got, ref = _both(pu, pd, reads * 50, 6, mode)
+        assert_same(got, ref, f"all mode {mode}", rcount=(mode == 0))
+        assert got["pairs"] == ref["pairs"]
+        assert all(v > 0 for v in ref["branch"].values())
+
+
+def test_refid_above_n_genomes_is_an_error(tmp_path):
+    pu, pd = build_index(tmp_path, {b"ACGTACG": (5, 1)}, {}, 6)
+    b, o = synth.concat_reads([b"ACGTACGT"])
+    with pytest.raises(cq.CammiqError) as e:
+        cq.Index(pu, pd, device=0).query(b, o, 4)
+    assert e.value.code == -5
+
+
+def test_size_independent_properties_at_scale(tmp_path):
+    """BASELINE-sized batches are beyond the oracle's reach in seconds; check what must hold
+    at any size: shard additivity (the multi-GPU contract), permutation invariance, every
+    read lands in exactly one outcome, device API == host API."""
+    import torch
+    gen = synth.clade_genomes(77, 4, 3, 4000, 0.03)
+    u, d = synth.select_markers(gen, 26, 40, keep_every=3, seed=7)
+    pu, pd = build_index(tmp_path, u, d, 26)
+    G = len(gen)
+    base = synth.simulate_reads(gen, 20000, 100, 0.01, 11, frac_random=0.1)
+    reads = base * 25                       # 500k reads
+    b, o = synth.concat_reads(reads)
+    ix = cq.Index(pu, pd, device=0)
+    whole = ix.query(b, o, G)
+    # oracle on the 20k base; the 25-fold repeat must be exactly 25x
+    ref = oracle_lib.OracleIndex(pu, pd).query(*synth.concat_reads(base), G)
+    for k in ("cnt_u", "cnt_d", "rcount_u", "rcount_d"):
+        assert np.array_equal(whole[k], ref[k] * 25), k
+    assert whole["nundet"] == 25 * ref["nundet"] and whole["nconf"] == 25 * ref["nconf"]
+    # shards add up
+    n = len(reads)
+    acc = None
+    for lo, hi in ((0, n // 3), (n // 3, n // 3 + 7), (n // 3 + 7, n)):
+        part = ix.query(*synth.concat_reads(reads[lo:hi]), G)
+        if acc is None:
+            acc = {k: (v.copy() if hasattr(v, "copy") else v) for k, v in part.items()}
+        else:
+            for k in ("cnt_u", "cnt_d", "rcount_u", "rcount_d"):
+                acc[k] += part[k]
+            acc["nundet"] += part["nundet"]; acc["nconf"] += part["nconf"]
+    assert_same(acc, whole, "shards")
+    # permutation invariance
+    rng = np.random.default_rng(0)
+    perm = [reads[i] for i in rng.permutation(n)]
+    assert_same(ix.query(*synth.concat_reads(perm), G), whole, "permuted")
+    # conservation: each read is counted, undetermined or conflicting -- exactly one of them
+    counted = sum(ref["branch"][k] for k in ("U1_P0", "U0_P1", "U1_Pall", "U0_PI1"))
+    assert counted + ref["nundet"] + ref["nconf"] == len(base)
+    # device-resident API (what bench.py and a multi-GPU host use) == host API
+    packed, lens, sk = cq.pack_reads(b, o, ix.hash_len)
+    assert sk == 0
+    dp = torch.from_numpy(packed.view(np.int32)).cuda()
+    dl = torch.from_numpy(lens).cuda()
+    ctr = torch.zeros(ix.counter_words(G), dtype=torch.int64, device="cuda")
+    rc = torch.zeros(sum(ix.n_leaves), dtype=torch.int32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    half = n // 2
+    ix.query_device(0, dp.data_ptr(), dl.data_ptr(), half, packed.shape[1], 100, G, ctr.data_ptr(), rc.data_ptr(), st)
+    ix.query_device(0, dp[half:].data_ptr(), dl[half:].data_ptr(), n - half, packed.shape[1], 100, G,
+                    ctr.data_ptr(), rc.data_ptr(), st)
+    torch.cuda.synchronize()
+    c = ctr.cpu().numpy().astype(np.uint64)
+    got = dict(cnt_u=c[:G + 1], cnt_d=c[G + 1:2 * G + 2], nundet=int(c[2 * G + 2]), nconf=int(c[2 * G + 3]),
+               rcount_u=rc.cpu().numpy().view(np.uint32)[:ix.n_leaves[0]],
+               rcount_d=rc.cpu().numpy().view(np.uint32)[ix.n_leaves[0]:])
+    assert_same(got, whole, "device api")
+    assert ix.last_kernel_ms() > 0

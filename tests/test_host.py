@@ -1,0 +1,174 @@
+"""CPU-side tests of the product: the C ABI loads and exports what include/cammiq_hip.h
+declares, the decoder + flat layout + packer are right, errors come back as status codes.
+No compute call is made here (no GPU in this container)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import cammiq_amd as cq
+from cammiq_amd import binding, synth
+import oracle_lib
+import pyref
+from util import build_index, golden
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "cammiq_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(cq_[a-z_0-9]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    L = C.CDLL(binding.lib_path())
+    for name in declared:
+        assert hasattr(L, name), f"{name} declared in cammiq_hip.h but not exported"
+    assert declared == set(binding.SIGNATURES), (declared ^ set(binding.SIGNATURES))
+    assert binding.lib().cq_abi_version() == 1
+
+
+def test_oracle_is_not_linked_into_the_product():
+    out = os.popen(f"nm -D {binding.lib_path()}").read()
+    assert "cqo_" not in out
+    src = os.path.join(ROOT, "cammiq_amd")
+    for dp, _, fs in os.walk(src):
+        for f in fs:
+            if f.endswith((".py", ".cpp", ".hip", ".h", ".hpp")):
+                txt = open(os.path.join(dp, f), errors="ignore").read()
+                assert "oracle_lib" not in txt and "liboracle" not in txt and "cqo_" not in txt, f
+
+
+@pytest.mark.parametrize("name", ["f_deep", "f_flat", "survey_F1", "survey_F2"])
+def test_decoder_matches_oracle_and_pyref(name):
+    g = golden(name)
+    ix = cq.Index(g["pu"], g["pd"], device=-1)
+    oi = oracle_lib.OracleIndex(g["pu"], g["pd"])
+    assert ix.hash_len == oi.hash_len and ix.n_leaves == oi.n_leaves
+    assert list(ix.info.n_file_buckets) == oi.n_buckets
+    for t in (0, 1):
+        a, b = ix.leaves(t), oi.leaves(t)
+        for f in ("refID1", "refID2", "depth", "ucount1", "ucount2"):
+            assert np.array_equal(a[f], b[f]), (t, f)
+    # the table finds every bucket, with the right root code for depth-0 keys, and nothing else
+    h = ix.hash_len
+    nu = ix.n_leaves[0]
+    hv = lambda key: int("".join("{:02b}".format(synth.SYM[c]) for c in key[:h]), 2)
+    tabs = [pyref.decode_index(g["pu"])[2], pyref.decode_index(g["pd"])[2] if g["pd"] else []]
+    present = [set(), set()]
+    for t in (0, 1):
+        for i, (key, *_r) in enumerate(tabs[t]):
+            present[t].add(hv(key))
+            if len(key) == h:
+                code = ix.probe(hv(key))[t]
+                assert code == (0x80000000 | (i + (nu if t else 0)))
+    for k in present[0] | present[1]:
+        cu, cd, chain = ix.probe(k)
+        assert (cu != 0) == (k in present[0]) and (cd != 0) == (k in present[1])
+        assert 1 <= chain <= ix.info.max_chain
+    rng = np.random.default_rng(1)
+    for k in rng.integers(0, 1 << (2 * h), size=5000):
+        cu, cd, _ = ix.probe(int(k))
+        assert (cu != 0) == (int(k) in present[0]) and (cd != 0) == (int(k) in present[1])
+    i = ix.info_dict()
+    assert i["n_keys"] == len(present[0] | present[1])
+    assert i["n_overflowed"] < 0.05 * i["n_table_buckets"]
+
+
+def test_duplicate_bucket_later_wins(tmp_path):
+    """map64[bucket] = root overwrites (hashtrie.cpp:500): craft a file with the same bucket twice."""
+    s = synth._Sink()
+    s.bit(0); s.bits(7, 64); s.bits(8, 6)
+    hv = int("000110110001", 2)  # ACGTAC
+    for rid in (7, 9):
+        s.u64(hv)
+        s.bit(1)
+        for _ in range(4):
+            s.bit(0)
+        s.u32(rid); s.u16(1)
+    s.flush64()
+    p = str(tmp_path / "dup.bin1")
+    open(p, "wb").write(bytes(s.ints)); open(p + ".aux", "wb").write(bytes(s.aux))
+    ix = cq.Index(p, None, device=-1)
+    assert ix.n_leaves == [2, 0] and list(ix.leaves(0)["refID1"]) == [7, 9]
+    assert ix.probe(hv)[0] == (0x80000000 | 1)
+    oi = oracle_lib.OracleIndex(p, None)
+    b, o = synth.concat_reads([b"ACGTACGG"])
+    assert list(map(int, oi.query(b, o, 9)["rcount_u"])) == [0, 1]
+
+
+def test_load_errors(tmp_path):
+    with pytest.raises(cq.CammiqError) as e:
+        cq.Index(str(tmp_path / "nope.bin1"), None, device=-1)
+    assert e.value.code == -2 and "Cannot open file" in str(e.value)
+    pu, pd = build_index(tmp_path, {b"ACGTACG": (1, 1)}, {b"ACGTACGA": (1, 2, 1, 1)}, 6, "m")
+    # truncated byte stream
+    raw = open(pu, "rb").read()
+    open(pu, "wb").write(raw[:11])
+    with pytest.raises(cq.CammiqError) as e:
+        cq.Index(pu, None, device=-1)
+    assert e.value.code == -3
+    open(pu, "wb").write(raw)
+    # truncated bit stream
+    aux = open(pu + ".aux", "rb").read()
+    open(pu + ".aux", "wb").write(aux[:2])
+    with pytest.raises(cq.CammiqError) as e:
+        cq.Index(pu, None, device=-1)
+    assert e.value.code == -3
+    open(pu + ".aux", "wb").write(aux)
+    # hash length mismatch between the two files (assert at query.cpp:460)
+    pu2, pd2 = build_index(tmp_path, {b"ACGTACG": (1, 1)}, {b"ACGTACGA": (1, 2, 1, 1)}, 7, "m7")
+    with pytest.raises(cq.CammiqError) as e:
+        cq.Index(pu, pd2, device=-1)
+    assert e.value.code == -4
+    # header option != 64
+    open(pu + ".aux", "wb").write(bytes([0x3F]) + aux[1:])
+    with pytest.raises(cq.CammiqError) as e:
+        cq.Index(pu, None, device=-1)
+    assert e.value.code == -3
+
+
+def test_no_cpu_fallback(tmp_path):
+    """A host-only handle must refuse to classify; there is no CPU path to fall back to."""
+    pu, pd = build_index(tmp_path, {b"ACGTACG": (1, 1)}, {}, 6, "n")
+    ix = cq.Index(pu, None, device=-1)
+    b, o = synth.concat_reads([b"ACGTACGT"])
+    with pytest.raises(cq.CammiqError) as e:
+        ix.query(b, o, 1)
+    assert e.value.code == -6
+
+
+def test_packer():
+    reads = [b"ACGT" * 8, b"acgtACGTTTGA", b"ACGTN", b"AC", b"T" * 255, b"G" * 256, b"ACGT\xe6ACGT", b""]
+    b, o = synth.concat_reads(reads)
+    h = 4
+    packed, lens, sk = cq.pack_reads(b, o, h)
+    assert packed.shape == (len(reads), 16)
+    assert list(lens) == [32, 12, 0, 0, 255, 0, 0, 0] and sk == 5
+    for r, read in enumerate(reads):
+        if lens[r] == 0:
+            assert not packed[r].any()
+            continue
+        for j, c in enumerate(read):
+            got = (int(packed[r, j >> 4]) >> (30 - 2 * (j & 15))) & 3
+            assert got == synth.SYM[c]
+        # bits past the end are zero
+        full = int.from_bytes(packed[r].astype(">u4").tobytes(), "big")
+        assert full & ((1 << (16 * 32 - 2 * len(read))) - 1) == 0
+    assert cq.stride_words(100) == 8 and cq.stride_words(150) == 12 and cq.stride_words(255) == 16
+    assert cq.stride_words(1) == 4 and cq.stride_words(64) == 4 and cq.stride_words(65) == 8
+
+
+def test_packer_large_multithreaded():
+    rng = np.random.default_rng(0)
+    n, L = 70000, 100
+    bases = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, size=n * L)]
+    offs = (np.arange(n + 1, dtype=np.uint64) * L)
+    packed, lens, sk = cq.pack_reads(bases, offs, 26)
+    assert sk == 0 and (lens == L).all()
+    sym = np.searchsorted(np.frombuffer(b"ACGT", np.uint8), bases).reshape(n, L).astype(np.uint32)
+    want = np.zeros((n, 8), np.uint32)
+    for j in range(L):
+        want[:, j >> 4] |= sym[:, j] << np.uint32(30 - 2 * (j & 15))
+    assert np.array_equal(packed, want)

@@ -1,0 +1,153 @@
+"""The oracle (oracle/cammiq_oracle.c) against (a) the committed golden fixtures, (b) the
+independent brute-force statement tests/pyref.py, (c) the numbers SURVEY.md records for the
+reference on the survey fixtures, (d) hand-made cases for every branch of the decision rule."""
+import os
+
+import numpy as np
+import pytest
+
+from cammiq_amd import synth
+import oracle_lib
+import pyref
+from util import assert_same, build_index, golden
+
+
+@pytest.mark.parametrize("name", ["f_deep", "f_flat"])
+def test_oracle_matches_golden(name):
+    g = golden(name)
+    ix = oracle_lib.OracleIndex(g["pu"], g["pd"])
+    assert ix.hash_len == g["exp"]["hash_len"] and ix.n_leaves == g["exp"]["n_leaves"]
+    b, o = synth.concat_reads(g["reads"])
+    for threads in (1, 3):
+        got = ix.query(b, o, g["G"], mode=0, nthreads=threads)
+        assert_same(got, g["exp"]["p"], f"{name} t={threads}")
+        assert got["branch"] == g["exp"]["p"]["branch"]
+    sc = ix.query(b, o, g["G"], mode=1)
+    assert_same(sc, g["exp"]["sc"], name + " sc", rcount=False)
+    assert sorted([a, b_, c] for (a, b_), c in sc["pairs"].items()) == g["exp"]["sc"]["pairs"]
+    assert int(sc["rcount_u"].sum()) == 0 and int(sc["rcount_d"].sum()) == 0
+
+
+def test_oracle_reproduces_survey_numbers():
+    """Informational cross-check (see tests/golden/make_golden.py): indices written by the
+    reference's build, reads and expected numbers as recorded in SURVEY.md 8(c)."""
+    g = golden("survey_F1")
+    ix = oracle_lib.OracleIndex(g["pu"], g["pd"])
+    b, o = synth.concat_reads(g["reads"])
+    r = ix.query(b, o, g["G"])
+    s = g["exp"]["survey"]
+    assert list(map(int, r["cnt_u"])) == s["cnt_u"] and r["nundet"] == s["nundet"]
+    sc = ix.query(b, o, g["G"], mode=1)   # --read_cnts TSV channel: 412 317 404 417
+    assert list(map(int, sc["cnt_u"])) == s["cnt_u"]
+
+    g = golden("survey_F2")
+    ix = oracle_lib.OracleIndex(g["pu"], g["pd"])
+    b, o = synth.concat_reads(g["reads"])
+    r = ix.query(b, o, g["G"])
+    s = g["exp"]["survey"]
+    assert r["nundet"] == s["nundet"] and r["nconf"] == s["nconf"]
+    assert r["branch"] == s["branch"]
+    assert int(r["rcount_u"].sum()) == s["sum_rcount_u"]
+    # every d-leaf sits in two map_sp lists (hashtrie.cpp:452-453)
+    assert 2 * int(r["rcount_d"].sum()) == s["sum_rcount_d_over_map_sp"]
+    assert ix.n_leaves == [10492, 9108]
+
+
+def test_oracle_vs_bruteforce_random(tmp_path):
+    gen = synth.clade_genomes(21, 2, 3, 2500, 0.04)
+    u, d = synth.select_markers(gen, 14, 30, keep_every=2, seed=4)
+    for h in (8, 14):
+        pu, pd = build_index(tmp_path, u, d, h, name=f"h{h}")
+        reads = synth.simulate_reads(gen, 600, (14, 200), 0.02, 8, frac_random=0.2, lower_frac=0.2)
+        b, o = synth.concat_reads(reads)
+        ix = oracle_lib.OracleIndex(pu, pd)
+        for mode, pm in ((0, "p"), (1, "sc")):
+            got = ix.query(b, o, len(gen), mode=mode)
+            ref = pyref.classify(pu, pd, reads, len(gen), pm)
+            assert_same(got, ref, f"h={h} mode={pm}")
+            assert got["pairs"] == (ref["pairs"] if mode else {}) or mode == 0
+
+
+def _mk(h, spec_u, spec_d, tmp_path, name):
+    """spec: {key bytes: record}"""
+    return build_index(tmp_path, spec_u, spec_d, h, name=name)
+
+
+def test_every_branch_of_the_decision_rule(tmp_path):
+    """Hand-made 6-mer index (h=6): one read per outcome of query.cpp:542-636."""
+    K = {n: s for n, s in zip("abcdefgh", [b"AAAAAC", b"AAAACC", b"AAACCC", b"AACCCC", b"ACCCCC",
+                                           b"CCCCCA", b"CCCCAA", b"CCCAAT"])}
+    u = {K["a"]: (1, 1), K["b"]: (2, 1), b"GGGGGGT": (3, 1)}
+    d = {K["c"]: (1, 2, 1, 1), K["d"]: (1, 3, 1, 1), K["e"]: (2, 3, 1, 1), K["f"]: (4, 5, 1, 1),
+         K["g"]: (6, 6, 1, 1)}
+    pu, pd = _mk(6, u, d, tmp_path, "br")
+    T = b"TTTTTT"   # filler; its reverse complement AAAAAA is no key
+    reads = {
+        "undet": T + b"GTGTGT",
+        "U1_P0": b"GTGT" + K["a"] + b"GT",
+        "Umulti": K["a"] + b"GT" + K["b"],
+        "U0_P1": b"GT" + K["c"] + b"GT",
+        "U1_Pall": K["a"] + b"G" + K["c"] + b"G" + K["d"],     # U={1}, P={(1,2),(1,3)}
+        "U1_Pconf": K["a"] + b"G" + K["e"],                     # U={1}, P={(2,3)}
+        "U0_PI1": K["c"] + b"G" + K["d"],                       # P={(1,2),(1,3)}, I={1}
+        "U0_Pconf": K["c"] + b"G" + K["f"],                     # P={(1,2),(4,5)}, I={}
+    }
+    ix = oracle_lib.OracleIndex(pu, pd)
+    for want, read in reads.items():
+        b, o = synth.concat_reads([read])
+        got = ix.query(b, o, 6)
+        hit = [k for k, v in got["branch"].items() if v]
+        assert hit == [want], (want, hit, read)
+        ref = pyref.classify(pu, pd, [read], 6)
+        assert_same(got, ref, want)
+    # deep key: GGGGGG + T needs the 7th base inside the read
+    for read, n in ((b"ACGGGGGGT", 1), (b"ACGGGGGG", 0), (b"ACCCCCCA"[::-1], 0)):
+        b, o = synth.concat_reads([read])
+        assert int(ix.query(b, o, 6)["cnt_u"][3]) == n
+    # reverse strand: a read holding the reverse complement of a key hits it
+    b, o = synth.concat_reads([synth.revcomp(b"GTGT" + K["a"] + b"GT")])
+    assert int(ix.query(b, o, 6)["cnt_u"][1]) == 1
+    # degenerate pair (a,a): one pair -> d[a] += 2 (query.cpp:559-560)
+    b, o = synth.concat_reads([b"GT" + K["g"] + b"GT"])
+    got = ix.query(b, o, 6)
+    assert int(got["cnt_d"][6]) == 2 and got["branch"]["U0_P1"] == 1
+    # both pairs (2-set intersection of size 2) -> conflict
+    d2 = {K["c"]: (1, 2, 1, 1), K["d"]: (2, 1, 1, 1), K["e"]: (1, 2, 3, 3)}
+    pu2, pd2 = _mk(6, {b"GGGGGGT": (3, 1)}, d2, tmp_path, "br2")
+    ix2 = oracle_lib.OracleIndex(pu2, pd2)
+    b, o = synth.concat_reads([K["c"] + b"G" + K["d"] + b"G" + K["e"]])
+    got = ix2.query(b, o, 3)    # three leaves, ONE distinct pair -> |P| = 1
+    assert got["branch"]["U0_P1"] == 1 and int(got["cnt_d"][1]) == 1 and int(got["cnt_d"][2]) == 1
+    assert list(map(int, got["rcount_d"])) == [1, 1, 1]
+
+
+def test_rcount_counts_distinct_leaves_once_per_read(tmp_path):
+    key = b"ACGTAC"          # its own... not a palindrome; appears twice + once reversed
+    u = {key: (1, 1)}
+    pu, pd = _mk(6, u, {}, tmp_path, "dup")
+    read = key + b"TT" + key + b"TT" + synth.revcomp(key)
+    ix = oracle_lib.OracleIndex(pu, pd)
+    b, o = synth.concat_reads([read, read])
+    got = ix.query(b, o, 1)
+    assert int(got["cnt_u"][1]) == 2 and list(map(int, got["rcount_u"])) == [2]
+
+
+def test_domain_errors(tmp_path):
+    pu, pd = _mk(6, {b"ACGTAC": (1, 1)}, {}, tmp_path, "dom")
+    ix = oracle_lib.OracleIndex(pu, pd)
+    for bad in (b"ACGTA", b"ACGTNACGT", b"A" * 256):
+        b, o = synth.concat_reads([b"ACGTACGT", bad])
+        with pytest.raises(ValueError):
+            ix.query(b, o, 1)
+    b, o = synth.concat_reads([b"ACGTACGT"])
+    with pytest.raises(ValueError):
+        ix.query(b, o, 0)      # refID 1 > n_genomes 0
+
+
+def test_empty_d_table_and_empty_input(tmp_path):
+    pu, _ = _mk(6, {b"ACGTAC": (1, 1)}, {}, tmp_path, "e")
+    ix = oracle_lib.OracleIndex(pu, None)
+    b, o = synth.concat_reads([])
+    got = ix.query(b, o, 1)
+    assert got["nundet"] == 0 and int(got["cnt_u"].sum()) == 0
+    assert ix.n_leaves == [1, 0]

@@ -1,0 +1,42 @@
+"""Shared helpers for the tests: golden fixtures and result comparison."""
+import gzip
+import json
+import os
+
+import numpy as np
+
+from cammiq_amd import synth
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def golden(name):
+    d = os.path.join(GOLDEN, name)
+    reads = gzip.open(os.path.join(d, "reads.txt.gz"), "rb").read().split()
+    exp = json.load(open(os.path.join(d, "expected.json")))
+    pu = os.path.join(d, "index_u.bin1")
+    pd = os.path.join(d, "index_d.bin2")
+    if not os.path.exists(pd):
+        pd = None
+    return dict(dir=d, pu=pu, pd=pd, reads=reads, exp=exp, G=exp["n_genomes"])
+
+
+def assert_same(got, ref, what="", rcount=True):
+    for k in ("cnt_u", "cnt_d") + (("rcount_u", "rcount_d") if rcount else ()):
+        a = np.asarray(got[k]).astype(np.uint64)
+        b = np.asarray(ref[k]).astype(np.uint64)
+        assert a.shape == b.shape, f"{what}: {k} shape {a.shape} vs {b.shape}"
+        if not np.array_equal(a, b):
+            bad = np.nonzero(a != b)[0]
+            raise AssertionError(f"{what}: {k} differs at {bad[:8]} (got {a[bad[:8]]}, want {b[bad[:8]]}), "
+                                 f"{len(bad)} of {len(a)}")
+    assert got["nundet"] == ref["nundet"], f"{what}: nundet {got['nundet']} vs {ref['nundet']}"
+    assert got["nconf"] == ref["nconf"], f"{what}: nconf {got['nconf']} vs {ref['nconf']}"
+
+
+def build_index(tmpdir, keys_u, keys_d, h, name="ix", seed=0):
+    pu = os.path.join(str(tmpdir), f"{name}_u.bin1")
+    pd = os.path.join(str(tmpdir), f"{name}_d.bin2")
+    synth.write_index(pu, keys_u, h, False, order_seed=seed)
+    synth.write_index(pd, keys_d, h, True, order_seed=seed + 1)
+    return pu, pd
