@@ -112,6 +112,7 @@ int upload(cq_index *ix)
     ix->dev.leaf_rids = (const uint2 *)ix->d_leaf_rids;
     ix->dev.n_buckets = (uint32_t)img.n_buckets;
     ix->dev.hash_len = img.hash_len;
+    ix->dev.minimizer_len = cq_minimizer_len(img.hash_len);
     return CQ_OK;
 }
 

@@ -28,8 +28,72 @@ typedef struct cq_slot {
     uint32_t val_d;
 } cq_slot;
 
-/* Home bucket of a key.  32-bit mixing only (64-bit multiplies are multi-instruction on
- * CDNA); the range reduction is a multiply-high, so n_buckets need not be a power of two. */
+/* ---- minimizer addressing -------------------------------------------------------------
+ * A window's forward h-mer F and its reverse complement R are BOTH looked up (the reference
+ * scans both strands, query.cpp:480-527), and neighbouring windows overlap in h-1 bases.
+ * Keys are therefore not placed by hash(key) but by hash(minimizer(key)): the canonical
+ * m-mer (m = min(h, 15)) that minimises a bijective 32-bit hash phi over all m-mers of the
+ * key and of its reverse complement (only the minimum phi itself is used).  Consequences:
+ *   * F and R have the same minimizer -> ONE bucket chain serves both strand lookups;
+ *   * consecutive windows share their minimizer for ~(h-m+2)/2 positions -> adjacent lanes
+ *     read the SAME 64-byte bucket and the memory system serves them with one HBM access.
+ * Random HBM accesses per read drop from 2(rl-h+1) to about 2(rl-h+1)/(h-m+2)  (150 -> ~12
+ * for rl=100, h=26); lookups stay exact because every slot still holds the full key. */
+#define CQ_MAX_MINIMIZER 15
+
+CQ_HD uint32_t cq_minimizer_len(uint32_t h) { return h < CQ_MAX_MINIMIZER ? h : CQ_MAX_MINIMIZER; }
+
+/* Reverse the order of the 32 two-bit symbols of x. */
+CQ_HD uint64_t cq_rev2(uint64_t x)
+{
+    x = ((x >> 2) & 0x3333333333333333ull) | ((x & 0x3333333333333333ull) << 2);
+    x = ((x >> 4) & 0x0F0F0F0F0F0F0F0Full) | ((x & 0x0F0F0F0F0F0F0F0Full) << 4);
+    return __builtin_bswap64(x);
+}
+
+/* Reverse complement of the h-symbol string in the low 2h bits of x (A<->T, C<->G = 3-s). */
+CQ_HD uint64_t cq_revcomp(uint64_t x, uint32_t h) { return (~cq_rev2(x)) >> (64u - 2u * h); }
+
+/* Bijection on 32 bits (odd multiplies + xorshifts): equal phi <=> equal m-mer, so the
+ * minimum is unambiguous and identical for a key and its reverse complement. */
+CQ_HD uint32_t cq_phi32(uint32_t c)
+{
+    c *= 0x9E3779B1u; c ^= c >> 15;
+    c *= 0x85EBCA6Bu; c ^= c >> 13;
+    return c;
+}
+
+/* Reverse the order of the 16 two-bit symbols of a 32-bit word. */
+CQ_HD uint32_t cq_rev2_32(uint32_t x)
+{
+    x = ((x >> 2) & 0x33333333u) | ((x & 0x33333333u) << 2);
+    x = ((x >> 4) & 0x0F0F0F0Fu) | ((x & 0x0F0F0F0Fu) << 4);
+    return __builtin_bswap32(x);
+}
+
+/* phi of the canonical form of the m-mer f (m <= 15, f in the low 2m bits). */
+CQ_HD uint32_t cq_mmer_phi(uint32_t f, uint32_t m)
+{
+    const uint32_t r = (~cq_rev2_32(f)) >> (32u - 2u * m);
+    return cq_phi32(f < r ? f : r);
+}
+
+/* Minimizer hash of an h-mer: min of cq_mmer_phi over its h-m+1 m-mers.  Strand symmetric:
+ * the m-mers of the reverse complement are the reverse complements of these m-mers. */
+CQ_HD uint32_t cq_min_phi(uint64_t hmer, uint32_t h, uint32_t m)
+{
+    const uint32_t mask = (1u << (2u * m)) - 1u;
+    uint32_t best = 0xFFFFFFFFu;
+    for (uint32_t j = 0; j + m <= h; j++) {
+        const uint32_t p = cq_mmer_phi((uint32_t)(hmer >> (2u * (h - m - j))) & mask, m);
+        best = p < best ? p : best;
+    }
+    return best;
+}
+
+/* Home bucket of a minimizer hash.  min_phi is biased towards small values (it is a
+ * minimum), so it goes through a second mix; the range reduction is a multiply-high, so
+ * n_buckets need not be a power of two. */
 CQ_HD uint32_t cq_hash32(uint64_t k)
 {
     uint32_t lo = (uint32_t)k, hi = (uint32_t)(k >> 32);
@@ -40,9 +104,19 @@ CQ_HD uint32_t cq_hash32(uint64_t k)
     return x;
 }
 
-CQ_HD uint32_t cq_home_bucket(uint64_t k, uint32_t n_buckets)
+CQ_HD uint32_t cq_bucket_of_minimizer(uint32_t min_phi, uint32_t n_buckets)
 {
-    return (uint32_t)(((uint64_t)cq_hash32(k) * (uint64_t)n_buckets) >> 32);
+    uint32_t x = (min_phi ^ 0x5BD1E995u) * 0xC2B2AE35u;
+    x ^= x >> 15; x *= 0x27D4EB2Fu;
+    x ^= x >> 13; x *= 0x165667B1u;
+    x ^= x >> 16;
+    return (uint32_t)(((uint64_t)x * (uint64_t)n_buckets) >> 32);
+}
+
+/* Home bucket of an h-mer key (host side; the kernel has fw and rc at hand already). */
+CQ_HD uint32_t cq_home_bucket(uint64_t key, uint32_t h, uint32_t n_buckets)
+{
+    return cq_bucket_of_minimizer(cq_min_phi(key, h, cq_minimizer_len(h)), n_buckets);
 }
 
 /* Layout of the device counter block (uint64 words) for G = n_genomes:

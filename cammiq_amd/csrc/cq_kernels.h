@@ -16,6 +16,7 @@ struct DevIndex {
     const uint2 *leaf_rids;  // global leaf id -> (refID1, refID2)
     uint32_t n_buckets;      // hash range
     uint32_t hash_len;
+    uint32_t minimizer_len;  // cq_minimizer_len(hash_len)
 };
 
 struct QueryArgs {
@@ -24,6 +25,9 @@ struct QueryArgs {
     uint64_t n_reads;
     uint32_t stride_words;
     uint32_t wmax;           // max windows per read in this batch: max_len - h + 1
+    uint32_t pmax;           // max m-mer positions per read: max_len - m + 1   (set by the launcher)
+    uint32_t magic_w;        // ceil(2^32 / wmax), ceil(2^32 / pmax): exact small divisions
+    uint32_t magic_p;
     uint32_t n_genomes;
     int mode;
     uint64_t *counters;      // cq_counter_words(n_genomes)

@@ -5,22 +5,29 @@
 // Hash::find64_p (/root/reference/src/hashtrie.cpp:350-369) underneath -- but organised
 // for a 64-wide, memory-latency-bound machine instead of a pointer-chasing CPU loop:
 //
-//   * a workgroup takes a TILE of TR reads; their 2-bit rows are loaded coalesced and
-//     staged in LDS (the "sliding window" lives there, not in registers of one thread);
+//   * every WAVE takes a private sub-tile of R reads; their 2-bit rows are loaded coalesced
+//     and staged in LDS (the "sliding window" lives there, not in registers of one thread);
+//     waves never synchronise with each other inside the main loop;
+//   * a pre-pass hashes every m-mer position of the tile once (canonical form, bijective
+//     32-bit hash) into LDS; a window's MINIMIZER is then the minimum over h-m+1 adjacent
+//     LDS words instead of h-m+1 hash evaluations per window;
 //   * every lane owns ONE window position of one read and handles BOTH strands of it:
 //     the forward h-mer is a bit-field of the row, the reverse-complement h-mer is
 //     ~bitreverse of it, so no reverse-complement read is ever materialised
 //     (reference: getRC + a second scan, query.cpp:447-450,503-527);
-//   * each h-mer costs ONE 64-byte bucket read of the merged unique+doubly-unique table
-//     (reference: two find64_p calls = two hash lookups, query.cpp:487-492);
-//   * lanes that see a bucket hit (a few per cent) do not walk the trie in place: the
-//     wave compacts them with ballot + prefix popcount into an LDS work list and drains
-//     the list with full lanes, so divergent trie walks do not stall the probe stream;
+//   * the merged unique+doubly-unique table is addressed by the minimizer (cq_device.h):
+//     forward and reverse h-mer of a window share one 64-byte bucket, and so do runs of
+//     neighbouring windows = neighbouring lanes, whose identical loads the memory system
+//     serves with one HBM access (reference: four robin_hood lookups per window position,
+//     query.cpp:487-492,513-518);
+//   * lanes that see a bucket hit (a few per cent) do not walk the trie in place: they
+//     append to a per-wave LDS work list which the wave drains with full lanes, so the
+//     divergent, dependent trie walks do not stall the probe stream;
 //   * hits are gathered per read in LDS; one lane per read then de-duplicates them and
 //     applies the decision rule; per-genome counters are reduced in LDS and flushed with
 //     one global atomic per touched genome per workgroup; rcount uses global atomics.
 //
-// Integer only, HBM-latency/-bandwidth bound; MFMA is deliberately unused.
+// Integer only; MFMA is deliberately unused.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -33,8 +40,8 @@ namespace {
 
 constexpr int kBlock = 256;
 constexpr int kWaves = kBlock / 64;
-constexpr int kWorkCap = 320;   // per-wave work list: drain threshold 64 + 4 appends x 64 lanes
-constexpr int kWorkDrain = 64;
+constexpr int kWorkDrain = 64;   // drain a wave's list once it can fill the wave
+constexpr int kWorkCap = 160;    // items beyond the capacity are resolved in place by their lane
 
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 
@@ -56,20 +63,23 @@ __device__ __forceinline__ Bucket load_bucket(const uint4 *__restrict__ slots, u
     return r;
 }
 
-// Compare the four slots with `key`.  Returns true when the chain continues (overflow bit
-// set and key not found here).  vals.x = val_u, vals.y = val_d (0,0 when not found).
-__device__ __forceinline__ bool match_bucket(const Bucket &bk, uint64_t key, uint2 &vals)
+// Compare the four slots with the forward h-mer and with its reverse complement (both live
+// in the same bucket chain: same minimizer).  vf/vr = (val_u, val_d) of the slot holding
+// fw / rc.  Returns true when the chain continues: overflow bit set and not both found.
+__device__ __forceinline__ bool match_bucket(const Bucket &bk, uint64_t fw, uint64_t rc, uint2 &vf, uint2 &vr,
+                                             bool &ff, bool &fr)
 {
-    const uint32_t klo = (uint32_t)key, khi = (uint32_t)(key >> 32);
-    bool found = false;
+    const uint32_t flo = (uint32_t)fw, fhi = (uint32_t)(fw >> 32);
+    const uint32_t rlo = (uint32_t)rc, rhi = (uint32_t)(rc >> 32);
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         uint32_t shi = bk.s[k].y;
         if (k == 0) shi &= ~(1u << 30);  // strip CQ_OVERFLOW_BIT; an empty slot keeps bit 31
-        if (bk.s[k].x == klo && shi == khi) { vals.x = bk.s[k].z; vals.y = bk.s[k].w; found = true; }
+        if (bk.s[k].x == flo && shi == fhi) { vf.x = bk.s[k].z; vf.y = bk.s[k].w; ff = true; }
+        if (bk.s[k].x == rlo && shi == rhi) { vr.x = bk.s[k].z; vr.y = bk.s[k].w; fr = true; }
     }
     // overflow: bit 62 set, bit 63 clear on slot 0 (an EMPTY key has both set)
-    return !found && ((bk.s[0].y >> 30) == 1u);
+    return !(ff && fr) && ((bk.s[0].y >> 30) == 1u);
 }
 
 // Base q of a staged row (A=0..T=3).
@@ -78,38 +88,52 @@ __device__ __forceinline__ uint32_t row_base(const uint32_t *row, uint32_t q)
     return (row[q >> 4] >> (30u - 2u * (q & 15u))) & 3u;
 }
 
-// Word offsets of the per-workgroup LDS regions (shared by the kernel and its launcher).
-struct SmemLayout { uint32_t rows, len, hitcnt, hit_gid, hit_r1, hit_r2, scal, work, hist, total; };
+// LDS layout.  Every WAVE owns a private sub-tile of R reads (rows, m-mer hashes, hit lists,
+// work list): waves never wait for each other -- no __syncthreads in the main loop.  Only
+// the per-genome histogram and four scalar counters are shared by the workgroup (atomics).
+struct SmemLayout { uint32_t rows, phi, len, hitcnt, hit_gid, hit_r1, hit_r2, nwork, work, per_wave, scal, hist, total; };
 
-__host__ __device__ inline SmemLayout smem_layout(int TR, int CAP, uint32_t sw, uint32_t n_genomes, bool hist)
+__host__ __device__ inline SmemLayout smem_layout(int R, int CAP, uint32_t sw, uint32_t pmax, uint32_t n_genomes, bool hist)
 {
     SmemLayout L;
     uint32_t o = 0;
-    L.rows = o;    o += (uint32_t)TR * (sw + 2);
-    L.len = o;     o += (uint32_t)TR;
-    L.hitcnt = o;  o += (uint32_t)TR;
-    L.hit_gid = o; o += (uint32_t)TR * (uint32_t)CAP;
-    L.hit_r1 = o;  o += (uint32_t)TR * (uint32_t)CAP;
-    L.hit_r2 = o;  o += (uint32_t)TR * (uint32_t)CAP;
+    L.work = o;    o += 2u * kWorkCap;                 // uint2 list first: keeps it 8-byte aligned
+    L.rows = o;    o += (uint32_t)R * (sw + 2);
+    L.phi = o;     o += (uint32_t)R * pmax;
+    L.len = o;     o += (uint32_t)R;
+    L.hitcnt = o;  o += (uint32_t)R;
+    L.hit_gid = o; o += (uint32_t)R * (uint32_t)CAP;
+    L.hit_r1 = o;  o += (uint32_t)R * (uint32_t)CAP;
+    L.hit_r2 = o;  o += (uint32_t)R * (uint32_t)CAP;
+    L.nwork = o;   o += 1;
+    o = (o + 3u) & ~3u;                                // 16-byte multiple per wave
+    L.per_wave = o;
+    o *= kWaves;
     L.scal = o;    o += 4;
-    o += (o & 1u);                       // 8-byte align the uint2 work list
-    L.work = o;    o += 2u * kWaves * kWorkCap;
     L.hist = o;    if (hist) o += 2u * (n_genomes + 1u);
     L.total = o;
     return L;
 }
 
-struct Tile {
-    uint32_t *rows;      // [TR][swp]
-    uint32_t *len;       // [TR]   read length (0 = skip)
-    uint32_t *hitcnt;    // [TR]
-    uint32_t *hit_gid;   // [TR][CAP]
-    uint32_t *hit_r1;    // [TR][CAP]
-    uint32_t *hit_r2;    // [TR][CAP]
-    uint2 *work;         // [kWaves][kWorkCap]  .x = trie code, .y = read | strand<<8 | pos<<9
-    uint32_t *hist;      // [2*(G+1)] or null
-    uint32_t *scal;      // [4] nundet nconf nskipped nslow
+struct Tile {             // one wave's view of LDS
+    uint32_t *rows;      // [R][sw+2]  2-bit rows (+2 zero pad words)
+    uint32_t *phi;       // [R][pmax]  hash of the canonical m-mer starting at each base
+    uint32_t *len;       // [R]        read length (0 = skip)
+    uint32_t *hitcnt;    // [R]
+    uint32_t *hit_gid;   // [R][CAP]
+    uint32_t *hit_r1;    // [R][CAP]
+    uint32_t *hit_r2;    // [R][CAP]
+    uint32_t *nwork;     // [1]        length of this wave's work list
+    uint2 *work;         // [kWorkCap] .x = trie code, .y = read | strand<<8 | pos<<9
+    uint32_t *hist;      // [2*(G+1)] or null     (workgroup-shared)
+    uint32_t *scal;      // [4] nundet nconf nskipped nslow   (workgroup-shared)
 };
+
+// floor(idx / d) for idx < 2^16, d < 2^8 with magic = ceil(2^32 / d) (exact in that range).
+__device__ __forceinline__ uint32_t div_small(uint32_t idx, uint32_t d, uint32_t magic)
+{
+    return d == 1 ? idx : __umulhi(idx, magic);
+}
 
 // hashtrie.cpp:350-369 on the array trie.  `code` is the bucket root; returns the global
 // leaf id or 0xFFFFFFFF.  Forward strand consumes bases p+h, p+h+1, ...; the reverse strand
@@ -141,40 +165,36 @@ __device__ __forceinline__ void wave_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// Resolve the n items of this wave's work list with all 64 lanes: walk the trie (most codes
-// are depth-0 leaves already), fetch the leaf's refIDs, append to the read's hit list.
+// Resolve one candidate: walk the trie below the bucket root (most codes are depth-0 leaves
+// already), fetch the leaf's refIDs, append to the read's hit list.
 template <int CAP>
-__device__ __forceinline__ void drain_work(const DevIndex &ix, const Tile &t, uint32_t swp, uint32_t wave, uint32_t n)
+__device__ __forceinline__ void resolve(const DevIndex &ix, const Tile &t, uint32_t swp, uint32_t code, uint32_t meta)
 {
-    wave_sync();
-    const uint2 *wl = t.work + wave * kWorkCap;
-    for (uint32_t i = lane_id(); i < n; i += 64) {
-        uint2 it = wl[i];
-        uint32_t rl = it.y & 255u, strand = (it.y >> 8) & 1u, p = it.y >> 9;
-        uint32_t gid = walk_trie(ix, t.rows + rl * swp, t.len[rl], it.x, strand, p);
-        if (gid != 0xFFFFFFFFu) {
-            uint2 rr = ix.leaf_rids[gid];
-            uint32_t k = atomicAdd(&t.hitcnt[rl], 1u);
-            if (k < (uint32_t)CAP) {
-                t.hit_gid[rl * CAP + k] = gid;
-                t.hit_r1[rl * CAP + k] = rr.x;
-                t.hit_r2[rl * CAP + k] = rr.y;
-            }
+    const uint32_t rl = meta & 255u, strand = (meta >> 8) & 1u, p = meta >> 9;
+    const uint32_t gid = walk_trie(ix, t.rows + rl * swp, t.len[rl], code, strand, p);
+    if (gid != 0xFFFFFFFFu) {
+        const uint2 rr = ix.leaf_rids[gid];
+        const uint32_t k = atomicAdd(&t.hitcnt[rl], 1u);
+        if (k < (uint32_t)CAP) {
+            t.hit_gid[rl * CAP + k] = gid;
+            t.hit_r1[rl * CAP + k] = rr.x;
+            t.hit_r2[rl * CAP + k] = rr.y;
         }
     }
-    wave_sync();
 }
 
-// Wave-level compaction: every lane with `have` appends one item.  The list length `nw` is
-// wave-uniform and lives in a register (ballot gives every lane the same mask), so the
-// append needs no atomic at all.
-__device__ __forceinline__ void push_work(const Tile &t, uint32_t wave, uint32_t &nw, bool have, uint32_t code, uint32_t meta)
+// Drain this wave's work list with all 64 lanes.
+template <int CAP>
+__device__ __forceinline__ void drain_work(const DevIndex &ix, const Tile &t, uint32_t swp, uint32_t n)
 {
-    const uint64_t m = __ballot(have);
-    if (m == 0) return;
-    const uint32_t off = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
-    if (have) t.work[wave * kWorkCap + nw + off] = make_uint2(code, meta);
-    nw += (uint32_t)__popcll(m);
+    if (n > (uint32_t)kWorkCap) n = kWorkCap;
+    for (uint32_t i = lane_id(); i < n; i += 64) {
+        const uint2 it = t.work[i];
+        resolve<CAP>(ix, t, swp, it.x, it.y);
+    }
+    wave_sync();
+    if (lane_id() == 0) *t.nwork = 0;
+    wave_sync();
 }
 
 __device__ __forceinline__ void add_cnt(const QueryArgs &a, const Tile &t, uint32_t which, uint32_t rid)
@@ -264,129 +284,193 @@ __device__ __forceinline__ void decide(const QueryArgs &a, const Tile &t, uint32
 
 }  // namespace
 
-// TR reads per tile, CAP hit slots per read.  SLOW = exact path for reads whose hit list
-// overflowed CAP in the fast kernel: reads come from a device-side list, CAP covers the
-// worst case (2 strands x 2 tables x 251 windows).
-template <int TR, int CAP, bool SLOW>
+// One in-flight probe of a lane: which window, which bucket, and the bucket's 64 bytes.
+struct Probe {
+    bool act;
+    uint32_t rl, pw, b;
+    Bucket bk;
+};
+
+// R reads per wave sub-tile, CAP hit slots per read.  SLOW = exact path for reads whose hit
+// list overflowed CAP in the fast kernel: reads come from a device-side list, one per wave,
+// CAP covers the worst case (2 strands x 2 tables x 251 windows).
+template <int R, int CAP, bool SLOW>
 __global__ void __launch_bounds__(kBlock) classify_kernel(DevIndex ix, QueryArgs a)
 {
     extern __shared__ __align__(16) uint32_t smem[];
     const uint32_t sw = a.stride_words, swp = sw + 2;
     const uint32_t G1 = a.n_genomes + 1;
+    const uint32_t h = ix.hash_len, m = ix.minimizer_len, nphi = h - m + 1;
+    const uint32_t wmax = a.wmax, pmax = a.pmax;
+    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
+    const SmemLayout L = smem_layout(R, CAP, sw, pmax, a.n_genomes, a.use_lds_hist != 0);
+    uint32_t *mine = smem + wave * L.per_wave;
     Tile t;
-    const SmemLayout L = smem_layout(TR, CAP, sw, a.n_genomes, a.use_lds_hist != 0);
-    t.rows = smem + L.rows;
-    t.len = smem + L.len;
-    t.hitcnt = smem + L.hitcnt;
-    t.hit_gid = smem + L.hit_gid;
-    t.hit_r1 = smem + L.hit_r1;
-    t.hit_r2 = smem + L.hit_r2;
+    t.work = (uint2 *)(mine + L.work);
+    t.rows = mine + L.rows;
+    t.phi = mine + L.phi;
+    t.len = mine + L.len;
+    t.hitcnt = mine + L.hitcnt;
+    t.hit_gid = mine + L.hit_gid;
+    t.hit_r1 = mine + L.hit_r1;
+    t.hit_r2 = mine + L.hit_r2;
+    t.nwork = mine + L.nwork;
     t.scal = smem + L.scal;
-    t.work = (uint2 *)(smem + L.work);
     t.hist = a.use_lds_hist ? smem + L.hist : nullptr;
-
-    const uint32_t tid = threadIdx.x, wave = tid >> 6;
-    const uint32_t h = ix.hash_len;
 
     if (tid < 4) t.scal[tid] = 0;
     if (t.hist) for (uint32_t i = tid; i < 2 * G1; i += kBlock) t.hist[i] = 0;
+    if (lane == 0) *t.nwork = 0;
+    __syncthreads();   // the only workgroup barrier before the final flush
 
     uint64_t n_reads = a.n_reads;
     if (SLOW) n_reads = *a.ovf_count < a.ovf_cap ? *a.ovf_count : a.ovf_cap;
-    const uint64_t n_tiles = (n_reads + TR - 1) / TR;
-    const uint32_t wmax = a.wmax;
+    const uint64_t n_sub = (n_reads + R - 1) / R;
+    const uint64_t wave_gid = (uint64_t)blockIdx.x * kWaves + wave, n_waves = (uint64_t)gridDim.x * kWaves;
+    const uint32_t mmask = (1u << (2u * m)) - 1u;
 
-    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const uint64_t r0 = tile * TR;
-        const uint32_t nr = (uint32_t)((n_reads - r0) < (uint64_t)TR ? (n_reads - r0) : (uint64_t)TR);
-        __syncthreads();   // previous tile fully consumed (and the prologue's zeroing visible)
+    for (uint64_t sub = wave_gid; sub < n_sub; sub += n_waves) {
+        const uint64_t r0 = sub * R;
+        const uint32_t nr = (uint32_t)((n_reads - r0) < (uint64_t)R ? (n_reads - r0) : (uint64_t)R);
 
-        // ---- stage the tile: 2-bit rows -> LDS, coalesced (16 B per lane when direct)
+        // ---- stage the sub-tile: 2-bit rows -> LDS (16 B per lane, contiguous when direct)
         if (!SLOW) {
             const uint4 *src = (const uint4 *)(a.packed + r0 * sw);
             const uint32_t nvec = nr * (sw >> 2);
-            for (uint32_t i = tid; i < nvec; i += kBlock) {
-                uint4 v = src[i];
-                uint32_t w = i * 4, rl = w / sw, c = w - rl * sw;
+            for (uint32_t i = lane; i < nvec; i += 64) {
+                const uint4 v = src[i];
+                const uint32_t w = i * 4, rl = w / sw, c = w - rl * sw;
                 uint32_t *dst = t.rows + rl * swp + c;
                 dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
             }
         } else {
-            for (uint32_t i = tid; i < nr * sw; i += kBlock) {
-                uint32_t rl = i / sw, c = i - rl * sw;
+            for (uint32_t i = lane; i < nr * sw; i += 64) {
+                const uint32_t rl = i / sw, c = i - rl * sw;
                 t.rows[rl * swp + c] = a.packed[(uint64_t)a.ovf_list[r0 + rl] * sw + c];
             }
         }
-        for (uint32_t i = tid; i < TR; i += kBlock) {
+        if (lane < (uint32_t)R) {
             uint32_t len = 0;
-            if (i < nr) len = SLOW ? a.lens[a.ovf_list[r0 + i]] : a.lens[r0 + i];
-            t.len[i] = len;
-            t.hitcnt[i] = 0;
-            t.rows[i * swp + sw] = 0; t.rows[i * swp + sw + 1] = 0;   // pad words read by the window extract
+            if (lane < nr) len = SLOW ? a.lens[a.ovf_list[r0 + lane]] : a.lens[r0 + lane];
+            t.len[lane] = len;
+            t.hitcnt[lane] = 0;
+            t.rows[lane * swp + sw] = 0; t.rows[lane * swp + sw + 1] = 0;   // pad words read by the window extract
         }
-        __syncthreads();
+        wave_sync();
 
-        // ---- probe phase: lane = (read, window), both strands
-        const uint32_t total = nr * wmax;
-        uint32_t nw = 0;   // wave-uniform length of this wave's work list
-        for (uint32_t base = wave * 64; base < total; base += kBlock) {
-            const uint32_t idx = base + lane_id();
-            bool act = idx < total;
-            uint32_t rl = 0, pw = 0, len = 0;
-            if (act) {
-                rl = idx / wmax; pw = idx - rl * wmax;
-                len = t.len[rl];
-                act = (len >= h) && (pw + h <= len);
+        // ---- pre-pass: hash the canonical m-mer at every base position, once
+        {
+            const uint32_t total = nr * pmax;
+            for (uint32_t idx = lane; idx < total; idx += 64) {
+                const uint32_t rl = div_small(idx, pmax, a.magic_p), j = idx - rl * pmax;
+                if (j + m <= t.len[rl]) {
+                    const uint32_t *row = t.rows + rl * swp;
+                    const uint32_t q = j >> 4, s = (j & 15u) * 2u;
+                    const uint64_t x = ((uint64_t)row[q] << 32) | row[q + 1];
+                    t.phi[idx] = cq_mmer_phi((uint32_t)(x >> (64u - s - 2u * m)) & mmask, m);
+                }
             }
+        }
+        wave_sync();
+
+        // ---- probe phase: lane = (read, window), both strands, one bucket chain.
+        // Software-pipelined: the bucket of iteration i+1 is requested before iteration i is
+        // matched, so every lane keeps two 64-byte reads in flight.
+        const uint32_t total = nr * wmax;
+        auto prep = [&](uint32_t base, Probe &P) {
+            const uint32_t idx = base + lane;
+            P.act = idx < total;
+            P.rl = 0; P.pw = 0; P.b = 0;
+            if (P.act) {
+                P.rl = div_small(idx, wmax, a.magic_w);
+                P.pw = idx - P.rl * wmax;
+                const uint32_t len = t.len[P.rl];
+                P.act = (len >= h) && (P.pw + h <= len);
+            }
+            if (P.act) {
+                // minimizer hash = min over the h-m+1 m-mers of the window
+                const uint32_t *ph = t.phi + P.rl * pmax + P.pw;
+                uint32_t mp = ph[0];
+                for (uint32_t i = 1; i < nphi; i++) mp = min(mp, ph[i]);
+                P.b = cq_bucket_of_minimizer(mp, ix.n_buckets);
+                P.bk = load_bucket(ix.slots, P.b);
+            }
+        };
+        Probe cur;
+        prep(0, cur);
+        for (uint32_t base = 0; base < total; base += 64) {
+            Probe nxt;
+            nxt.act = false;
+            if (base + 64 < total) prep(base + 64, nxt);
             uint2 vf = make_uint2(0, 0), vr = make_uint2(0, 0);
-            if (act) {
-                const uint32_t *row = t.rows + rl * swp;
-                const uint32_t q = pw >> 4, s = (pw & 15u) * 2u;
+            if (cur.act) {
+                // forward h-mer = bit-field of the row; reverse complement = ~bitreverse
+                const uint32_t *row = t.rows + cur.rl * swp;
+                const uint32_t q = cur.pw >> 4, s = (cur.pw & 15u) * 2u;
                 const uint64_t x = ((uint64_t)row[q] << 32) | row[q + 1];
                 const uint64_t top = (x << s) | (((uint64_t)row[q + 2] << s) >> 32);
                 const uint64_t fw = top >> (64u - 2u * h);
                 const uint64_t rc = (~rev2(fw)) >> (64u - 2u * h);
-                uint32_t bf = cq_home_bucket(fw, ix.n_buckets), br = cq_home_bucket(rc, ix.n_buckets);
-                Bucket kf = load_bucket(ix.slots, bf);
-                Bucket kr = load_bucket(ix.slots, br);
-                bool cf = match_bucket(kf, fw, vf);
-                bool cr = match_bucket(kr, rc, vr);
-                while (cf) { kf = load_bucket(ix.slots, ++bf); cf = match_bucket(kf, fw, vf); }
-                while (cr) { kr = load_bucket(ix.slots, ++br); cr = match_bucket(kr, rc, vr); }
+                bool ff = false, fr = false;
+                uint32_t b = cur.b;
+                bool more = match_bucket(cur.bk, fw, rc, vf, vr, ff, fr);
+                while (more) {
+                    const Bucket bk = load_bucket(ix.slots, ++b);
+                    more = match_bucket(bk, fw, rc, vf, vr, ff, fr);
+                }
             }
-            // candidates -> wave work list (forward u, forward d, reverse u, reverse d)
-            const uint32_t mf = rl | (0u << 8) | (pw << 9), mr = rl | (1u << 8) | (pw << 9);
-            push_work(t, wave, nw, vf.x != 0, vf.x, mf);
-            push_work(t, wave, nw, vf.y != 0, vf.y, mf);
-            push_work(t, wave, nw, vr.x != 0, vr.x, mr);
-            push_work(t, wave, nw, vr.y != 0, vr.y, mr);
-            if (nw >= (uint32_t)kWorkDrain) { drain_work<CAP>(ix, t, swp, wave, nw); nw = 0; }
+            // candidates (forward u, forward d, reverse u, reverse d) -> this wave's work list.
+            // Few lanes have any, so the append is an LDS atomic by those lanes only; items
+            // that do not fit are resolved by their own lane right away.
+            const uint32_t ncand = (vf.x != 0) + (vf.y != 0) + (vr.x != 0) + (vr.y != 0);
+            if (ncand) {
+                uint32_t o = atomicAdd(t.nwork, ncand);
+                const uint32_t mf = cur.rl | (0u << 8) | (cur.pw << 9), mr = cur.rl | (1u << 8) | (cur.pw << 9);
+                const uint32_t code[4] = {vf.x, vf.y, vr.x, vr.y};
+                const uint32_t meta[4] = {mf, mf, mr, mr};
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    if (code[k]) {
+                        if (o < (uint32_t)kWorkCap) t.work[o] = make_uint2(code[k], meta[k]);
+                        else resolve<CAP>(ix, t, swp, code[k], meta[k]);
+                        o++;
+                    }
+            }
+            wave_sync();
+            const uint32_t nw = *(volatile uint32_t *)t.nwork;
+            if (nw >= (uint32_t)kWorkDrain) drain_work<CAP>(ix, t, swp, nw);
+            cur = nxt;
         }
-        if (nw != 0) drain_work<CAP>(ix, t, swp, wave, nw);
-        __syncthreads();
+        {
+            wave_sync();
+            const uint32_t nw = *(volatile uint32_t *)t.nwork;
+            if (nw != 0) drain_work<CAP>(ix, t, swp, nw);
+        }
+        wave_sync();
 
         // ---- decision phase: one lane per read
-        for (uint32_t rl = tid; rl < nr; rl += kBlock) {
-            const uint32_t len = t.len[rl];
-            if (len < h) { atomicAdd(&t.scal[2], 1u); continue; }   // outside the parity domain
-            const uint32_t n = t.hitcnt[rl];
-            if (n > (uint32_t)CAP) {
-                if (!SLOW) {   // hand the read to the exact slow path
-                    uint32_t k = atomicAdd(a.ovf_count, 1u);
-                    if (k < a.ovf_cap) a.ovf_list[k] = (uint32_t)(r0 + rl);
-                    atomicAdd(&t.scal[3], 1u);
-                }
-                continue;
+        if (lane < nr) {
+            const uint32_t len = t.len[lane];
+            if (len < h) atomicAdd(&t.scal[2], 1u);   // outside the parity domain
+            else {
+                const uint32_t n = t.hitcnt[lane];
+                if (n > (uint32_t)CAP) {
+                    if (!SLOW) {   // hand the read to the exact slow path
+                        const uint32_t k = atomicAdd(a.ovf_count, 1u);
+                        if (k < a.ovf_cap) a.ovf_list[k] = (uint32_t)(r0 + lane);
+                        atomicAdd(&t.scal[3], 1u);
+                    }
+                } else decide<CAP>(a, t, lane, n);
             }
-            decide<CAP>(a, t, rl, n);
         }
+        wave_sync();   // hit lists fully consumed before the next sub-tile resets them
     }
 
     // ---- flush workgroup-level counters
     __syncthreads();
     if (t.hist)
         for (uint32_t i = tid; i < 2 * G1; i += kBlock) {
-            uint32_t v = t.hist[i];
+            const uint32_t v = t.hist[i];
             if (v) atomicAdd((unsigned long long *)&a.counters[i], (unsigned long long)v);
         }
     if (tid < 4 && t.scal[tid]) {
@@ -396,12 +480,12 @@ __global__ void __launch_bounds__(kBlock) classify_kernel(DevIndex ix, QueryArgs
     }
 }
 
-constexpr int kFastTR = 64, kFastCAP = 16;
-constexpr int kSlowTR = 4, kSlowCAP = 1024;
+constexpr int kFastR = 8, kFastCAP = 16;
+constexpr int kSlowR = 1, kSlowCAP = 1024;
 
-static size_t smem_bytes(int TR, int CAP, uint32_t sw, uint32_t n_genomes, bool hist)
+static size_t smem_bytes(int R, int CAP, const QueryArgs &a, bool hist)
 {
-    return (size_t)smem_layout(TR, CAP, sw, n_genomes, hist).total * 4;
+    return (size_t)smem_layout(R, CAP, a.stride_words, a.pmax, a.n_genomes, hist).total * 4;
 }
 
 bool lds_hist_fits(uint32_t n_genomes)
@@ -409,20 +493,36 @@ bool lds_hist_fits(uint32_t n_genomes)
     return 2 * ((size_t)n_genomes + 1) * 4 <= 32 * 1024;
 }
 
+static uint32_t magic_of(uint32_t d) { return d <= 1 ? 0u : (uint32_t)((0x100000000ull + d - 1) / d); }
+
 hipError_t launch_classify(const DevIndex &ix, QueryArgs a, int n_cus, hipStream_t stream,
                            hipEvent_t ev_start, hipEvent_t ev_stop)
 {
     a.use_lds_hist = lds_hist_fits(a.n_genomes) ? 1 : 0;
+    a.pmax = a.wmax + (ix.hash_len - ix.minimizer_len);   // m-mer positions: max_len - m + 1
+    a.magic_w = magic_of(a.wmax);
+    a.magic_p = magic_of(a.pmax);
     hipError_t e;
-    // fast kernel
+    // LDS above the 64 KiB default needs an explicit opt-in (large G)
+    e = hipFuncSetAttribute((const void *)classify_kernel<kFastR, kFastCAP, false>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void *)classify_kernel<kSlowR, kSlowCAP, true>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    // fast kernel: persistent waves, each walking its own sub-tiles
     {
-        size_t sm = smem_bytes(kFastTR, kFastCAP, a.stride_words, a.n_genomes, a.use_lds_hist);
-        uint64_t n_tiles = (a.n_reads + kFastTR - 1) / kFastTR;
-        uint64_t grid = (uint64_t)n_cus * 4;
-        if (grid > n_tiles) grid = n_tiles;
+        const size_t sm = smem_bytes(kFastR, kFastCAP, a, a.use_lds_hist);
+        size_t per_cu = (160 * 1024) / (sm ? sm : 1);
+        if (per_cu > 8) per_cu = 8;
+        if (per_cu < 1) per_cu = 1;
+        const uint64_t n_sub = (a.n_reads + kFastR - 1) / kFastR;
+        uint64_t grid = (uint64_t)n_cus * per_cu;
+        const uint64_t need = (n_sub + kWaves - 1) / kWaves;
+        if (grid > need) grid = need;
         if (grid == 0) grid = 1;
         if (ev_start) { e = hipEventRecord(ev_start, stream); if (e != hipSuccess) return e; }
-        hipLaunchKernelGGL((classify_kernel<kFastTR, kFastCAP, false>), dim3((unsigned)grid), dim3(kBlock), sm, stream, ix, a);
+        hipLaunchKernelGGL((classify_kernel<kFastR, kFastCAP, false>), dim3((unsigned)grid), dim3(kBlock), sm, stream, ix, a);
         if (ev_stop) { e = hipEventRecord(ev_stop, stream); if (e != hipSuccess) return e; }
         e = hipGetLastError();
         if (e != hipSuccess) return e;
@@ -430,8 +530,8 @@ hipError_t launch_classify(const DevIndex &ix, QueryArgs a, int n_cus, hipStream
     // exact slow path for reads with more than kFastCAP hits (usually none: the kernel
     // reads the count from device memory and exits at once)
     {
-        size_t sm = smem_bytes(kSlowTR, kSlowCAP, a.stride_words, a.n_genomes, a.use_lds_hist);
-        hipLaunchKernelGGL((classify_kernel<kSlowTR, kSlowCAP, true>), dim3((unsigned)(n_cus)), dim3(kBlock), sm, stream, ix, a);
+        const size_t sm = smem_bytes(kSlowR, kSlowCAP, a, a.use_lds_hist);
+        hipLaunchKernelGGL((classify_kernel<kSlowR, kSlowCAP, true>), dim3((unsigned)(n_cus)), dim3(kBlock), sm, stream, ix, a);
         e = hipGetLastError();
     }
     return e;

@@ -6,9 +6,12 @@
 //   * ONE merged open-addressing table for ht_u and ht_d.  A slot is 16 B
 //     {key = hv, val_u, val_d}; 4 slots form a 64-byte bucket = one HBM access, so the two
 //     find64_p calls the reference makes per window (query.cpp:487-492) cost one probe.
+//     A key's home bucket is chosen by its canonical MINIMIZER (cq_device.h), not by the
+//     key itself: both strands of a window, and runs of neighbouring windows, then share one
+//     bucket, which cuts the random HBM accesses per read by an order of magnitude.
 //     Collisions stay inside the home bucket; a full bucket sets an overflow bit and spills
 //     to the next bucket(s).  A lookup that does not see the overflow bit stops after one
-//     bucket -- which is what >95 % of the (miss-dominated) probes do.
+//     bucket -- which is what most of the (miss-dominated) probes do.
 //   * a linked array trie (16-byte nodes, 4 child codes) for keys longer than h.
 //   * leaf refIDs as two flat uint32 arrays indexed by global leaf id (u leaves first).
 //
@@ -128,9 +131,9 @@ int build_image(const DecodedTable &u, const DecodedTable &d, double keys_per_bu
     std::vector<Entry> ent;
     ent.reserve(nb_u + nb_d);
     for (uint64_t i = 0; i < nb_u; i++)
-        ent.push_back(Entry{cq_home_bucket(u.bucket_key[i], n_buckets), (uint32_t)i, u.bucket_key[i], u.bucket_code[i], 0});
+        ent.push_back(Entry{cq_home_bucket(u.bucket_key[i], img.hash_len, n_buckets), (uint32_t)i, u.bucket_key[i], u.bucket_code[i], 0});
     for (uint64_t i = 0; i < nb_d; i++)
-        ent.push_back(Entry{cq_home_bucket(d.bucket_key[i], n_buckets), (uint32_t)i, d.bucket_key[i], 0, relink_d(d.bucket_code[i])});
+        ent.push_back(Entry{cq_home_bucket(d.bucket_key[i], img.hash_len, n_buckets), (uint32_t)i, d.bucket_key[i], 0, relink_d(d.bucket_code[i])});
     sort_entries(ent, n_buckets);
 
     // ---- merge duplicates (same key in both tables, or repeated within one file: the later
@@ -187,7 +190,7 @@ int build_image(const DecodedTable &u, const DecodedTable &d, double keys_per_bu
 void image_lookup(const FlatImage &img, uint64_t key, uint32_t &val_u, uint32_t &val_d, uint32_t *chain_len)
 {
     val_u = val_d = 0;
-    uint64_t b = cq_home_bucket(key, (uint32_t)img.n_buckets);
+    uint64_t b = cq_home_bucket(key, img.hash_len, (uint32_t)img.n_buckets);
     uint32_t chain = 0;
     for (;;) {
         const cq_slot *s = &img.slots[b * CQ_SLOTS_PER_BUCKET];
