@@ -66,7 +66,8 @@ SIGNATURES = {
 
 
 def lib_path() -> str:
-    return os.path.join(_HERE, "libcammiq_hip.so")
+    # CAMMIQ_LIB: kernel-tuning experiments load an alternative build of the same library
+    return os.environ.get("CAMMIQ_LIB") or os.path.join(_HERE, "libcammiq_hip.so")
 
 
 def lib():

@@ -20,9 +20,10 @@
 //     neighbouring windows = neighbouring lanes, whose identical loads the memory system
 //     serves with one HBM access (reference: four robin_hood lookups per window position,
 //     query.cpp:487-492,513-518);
-//   * lanes that see a bucket hit (a few per cent) do not walk the trie in place: they
-//     append to a per-wave LDS work list which the wave drains with full lanes, so the
-//     divergent, dependent trie walks do not stall the probe stream;
+//   * the hot loop only DETECTS (low-word compare of the four slots); the few windows
+//     that may hit are compacted with ballot + prefix popcount into a per-wave LDS work
+//     list, which the wave drains with full lanes: exact 64-bit compare, bucket chain,
+//     trie walk -- the divergent, dependent work never stalls the probe stream;
 //   * hits are gathered per read in LDS; one lane per read then de-duplicates them and
 //     applies the decision rule; per-genome counters are reduced in LDS and flushed with
 //     one global atomic per touched genome per workgroup; rcount uses global atomics.
@@ -41,7 +42,7 @@ namespace {
 constexpr int kBlock = 256;
 constexpr int kWaves = kBlock / 64;
 constexpr int kWorkDrain = 64;   // drain a wave's list once it can fill the wave
-constexpr int kWorkCap = 160;    // items beyond the capacity are resolved in place by their lane
+constexpr int kWorkCap = 128;    // an iteration appends at most one item per lane: 63 + 64 < 128
 
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 
@@ -168,10 +169,10 @@ __device__ __forceinline__ void wave_sync()
 // Resolve one candidate: walk the trie below the bucket root (most codes are depth-0 leaves
 // already), fetch the leaf's refIDs, append to the read's hit list.
 template <int CAP>
-__device__ __forceinline__ void resolve(const DevIndex &ix, const Tile &t, uint32_t swp, uint32_t code, uint32_t meta)
+__device__ __forceinline__ void resolve(const DevIndex &ix, const Tile &t, const uint32_t *row, uint32_t len,
+                                        uint32_t rl, uint32_t code, uint32_t strand, uint32_t p)
 {
-    const uint32_t rl = meta & 255u, strand = (meta >> 8) & 1u, p = meta >> 9;
-    const uint32_t gid = walk_trie(ix, t.rows + rl * swp, t.len[rl], code, strand, p);
+    const uint32_t gid = walk_trie(ix, row, len, code, strand, p);
     if (gid != 0xFFFFFFFFu) {
         const uint2 rr = ix.leaf_rids[gid];
         const uint32_t k = atomicAdd(&t.hitcnt[rl], 1u);
@@ -183,17 +184,43 @@ __device__ __forceinline__ void resolve(const DevIndex &ix, const Tile &t, uint3
     }
 }
 
-// Drain this wave's work list with all 64 lanes.
+// The exact lookup of one window (both strands): full 64-bit key compare along the bucket
+// chain, then trie walk + hit append for every table that holds the h-mer.  Runs only for
+// the few windows the probe loop flagged, one window per lane, all lanes busy.
+template <int CAP>
+__device__ __forceinline__ void lookup_window(const DevIndex &ix, const Tile &t, uint32_t swp, uint32_t rl,
+                                              uint32_t pw, uint32_t b)
+{
+    const uint32_t h = ix.hash_len;
+    const uint32_t *row = t.rows + rl * swp;
+    const uint32_t len = t.len[rl];
+    // forward h-mer = bit-field of the row; reverse complement = ~bitreverse
+    const uint32_t q = pw >> 4, s = (pw & 15u) * 2u;
+    const uint64_t x = ((uint64_t)row[q] << 32) | row[q + 1];
+    const uint64_t top = (x << s) | (((uint64_t)row[q + 2] << s) >> 32);
+    const uint64_t fw = top >> (64u - 2u * h);
+    const uint64_t rc = (~rev2(fw)) >> (64u - 2u * h);
+    uint2 vf = make_uint2(0, 0), vr = make_uint2(0, 0);
+    bool ff = false, fr = false, more;
+    do {
+        const Bucket bk = load_bucket(ix.slots, b++);
+        more = match_bucket(bk, fw, rc, vf, vr, ff, fr);
+    } while (more);
+    if (vf.x) resolve<CAP>(ix, t, row, len, rl, vf.x, 0, pw);   // ht_u, forward strand
+    if (vf.y) resolve<CAP>(ix, t, row, len, rl, vf.y, 0, pw);   // ht_d, forward strand
+    if (vr.x) resolve<CAP>(ix, t, row, len, rl, vr.x, 1, pw);   // ht_u, reverse strand
+    if (vr.y) resolve<CAP>(ix, t, row, len, rl, vr.y, 1, pw);   // ht_d, reverse strand
+}
+
+// Drain this wave's work list (n <= kWorkCap items: .x = bucket, .y = read | window << 8).
 template <int CAP>
 __device__ __forceinline__ void drain_work(const DevIndex &ix, const Tile &t, uint32_t swp, uint32_t n)
 {
-    if (n > (uint32_t)kWorkCap) n = kWorkCap;
+    wave_sync();
     for (uint32_t i = lane_id(); i < n; i += 64) {
         const uint2 it = t.work[i];
-        resolve<CAP>(ix, t, swp, it.x, it.y);
+        lookup_window<CAP>(ix, t, swp, it.y & 255u, it.y >> 8, it.x);
     }
-    wave_sync();
-    if (lane_id() == 0) *t.nwork = 0;
     wave_sync();
 }
 
@@ -284,13 +311,6 @@ __device__ __forceinline__ void decide(const QueryArgs &a, const Tile &t, uint32
 
 }  // namespace
 
-// One in-flight probe of a lane: which window, which bucket, and the bucket's 64 bytes.
-struct Probe {
-    bool act;
-    uint32_t rl, pw, b;
-    Bucket bk;
-};
-
 // R reads per wave sub-tile, CAP hit slots per read.  SLOW = exact path for reads whose hit
 // list overflowed CAP in the fast kernel: reads come from a device-side list, one per wave,
 // CAP covers the worst case (2 strands x 2 tables x 251 windows).
@@ -320,7 +340,6 @@ __global__ void __launch_bounds__(kBlock) classify_kernel(DevIndex ix, QueryArgs
 
     if (tid < 4) t.scal[tid] = 0;
     if (t.hist) for (uint32_t i = tid; i < 2 * G1; i += kBlock) t.hist[i] = 0;
-    if (lane == 0) *t.nwork = 0;
     __syncthreads();   // the only workgroup barrier before the final flush
 
     uint64_t n_reads = a.n_reads;
@@ -373,79 +392,64 @@ __global__ void __launch_bounds__(kBlock) classify_kernel(DevIndex ix, QueryArgs
         }
         wave_sync();
 
-        // ---- probe phase: lane = (read, window), both strands, one bucket chain.
-        // Software-pipelined: the bucket of iteration i+1 is requested before iteration i is
-        // matched, so every lane keeps two 64-byte reads in flight.
+        // ---- probe phase: lane = (read, window).  The hot loop only DETECTS: it reads the
+        // window's bucket and compares the low 32 key bits of the four slots with the low
+        // words of the forward and the reverse-complement h-mer.  Nearly every window stops
+        // here.  A window with a low-word match (a hit, up to a 2^-32 fluke) or with an
+        // overflowed bucket is appended to the wave's work list -- ballot + prefix popcount,
+        // the list length is wave-uniform and lives in a register -- and gets the exact
+        // treatment (lookup_window) once 64 of them are waiting.
         const uint32_t total = nr * wmax;
-        auto prep = [&](uint32_t base, Probe &P) {
+        const uint32_t lo_shift = h < 16 ? 32u - 2u * h : 0u;   // keys shorter than 32 bits
+        uint32_t nw = 0;
+        for (uint32_t base = 0; base < total; base += 64) {
             const uint32_t idx = base + lane;
-            P.act = idx < total;
-            P.rl = 0; P.pw = 0; P.b = 0;
-            if (P.act) {
-                P.rl = div_small(idx, wmax, a.magic_w);
-                P.pw = idx - P.rl * wmax;
-                const uint32_t len = t.len[P.rl];
-                P.act = (len >= h) && (P.pw + h <= len);
+            bool act = idx < total;
+            uint32_t rl = 0, pw = 0, b = 0;
+            bool flag = false;
+            if (act) {
+                rl = div_small(idx, wmax, a.magic_w);
+                pw = idx - rl * wmax;
+                const uint32_t len = t.len[rl];
+                act = (len >= h) && (pw + h <= len);
             }
-            if (P.act) {
+            if (act) {
                 // minimizer hash = min over the h-m+1 m-mers of the window
-                const uint32_t *ph = t.phi + P.rl * pmax + P.pw;
+                const uint32_t *ph = t.phi + rl * pmax + pw;
                 uint32_t mp = ph[0];
                 for (uint32_t i = 1; i < nphi; i++) mp = min(mp, ph[i]);
-                P.b = cq_bucket_of_minimizer(mp, ix.n_buckets);
-                P.bk = load_bucket(ix.slots, P.b);
+                b = cq_bucket_of_minimizer(mp, ix.n_buckets);
+                const Bucket bk = load_bucket(ix.slots, b);
+                // low word of the forward h-mer: the 32 bits that END at the window's end;
+                // low word of the reverse complement: ~reverse of the 32 bits that START it
+                const uint32_t *row = t.rows + rl * swp;
+                const uint32_t e = pw + h;                       // one past the last base
+                const uint32_t qe = e >> 4, se = (e & 15u) * 2u; // bit offset of the end in word qe
+                const uint32_t tail = qe ? (se ? __funnelshift_l(row[qe], row[qe - 1], se) : row[qe - 1])
+                                         : (row[0] >> (32u - se));
+                const uint32_t q = pw >> 4, s0 = (pw & 15u) * 2u;
+                const uint32_t head = s0 ? __funnelshift_l(row[q + 1], row[q], s0) : row[q];
+                const uint32_t hmask = lo_shift ? (0xFFFFFFFFu >> lo_shift) : 0xFFFFFFFFu;
+                const uint32_t flo = tail & hmask;
+                uint32_t y = __brev(head);
+                y = ((y >> 1) & 0x55555555u) | ((y & 0x55555555u) << 1);
+                // reversal puts the window's first base into the lowest symbol, so the low
+                // 2h bits are exactly the (whole, when h < 16) reverse complement
+                const uint32_t rlo = (~y) & hmask;
+                flag = (bk.s[0].x == flo) | (bk.s[1].x == flo) | (bk.s[2].x == flo) | (bk.s[3].x == flo) |
+                       (bk.s[0].x == rlo) | (bk.s[1].x == rlo) | (bk.s[2].x == rlo) | (bk.s[3].x == rlo) |
+                       ((bk.s[0].y >> 30) == 1u);
             }
-        };
-        Probe cur;
-        prep(0, cur);
-        for (uint32_t base = 0; base < total; base += 64) {
-            Probe nxt;
-            nxt.act = false;
-            if (base + 64 < total) prep(base + 64, nxt);
-            uint2 vf = make_uint2(0, 0), vr = make_uint2(0, 0);
-            if (cur.act) {
-                // forward h-mer = bit-field of the row; reverse complement = ~bitreverse
-                const uint32_t *row = t.rows + cur.rl * swp;
-                const uint32_t q = cur.pw >> 4, s = (cur.pw & 15u) * 2u;
-                const uint64_t x = ((uint64_t)row[q] << 32) | row[q + 1];
-                const uint64_t top = (x << s) | (((uint64_t)row[q + 2] << s) >> 32);
-                const uint64_t fw = top >> (64u - 2u * h);
-                const uint64_t rc = (~rev2(fw)) >> (64u - 2u * h);
-                bool ff = false, fr = false;
-                uint32_t b = cur.b;
-                bool more = match_bucket(cur.bk, fw, rc, vf, vr, ff, fr);
-                while (more) {
-                    const Bucket bk = load_bucket(ix.slots, ++b);
-                    more = match_bucket(bk, fw, rc, vf, vr, ff, fr);
-                }
+            const uint64_t mask = __ballot(flag);
+            if (mask) {
+                const uint32_t off = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
+                                                               __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
+                if (flag) t.work[nw + off] = make_uint2(b, rl | (pw << 8));
+                nw += (uint32_t)__popcll(mask);
+                if (nw >= (uint32_t)kWorkDrain) { drain_work<CAP>(ix, t, swp, nw); nw = 0; }
             }
-            // candidates (forward u, forward d, reverse u, reverse d) -> this wave's work list.
-            // Few lanes have any, so the append is an LDS atomic by those lanes only; items
-            // that do not fit are resolved by their own lane right away.
-            const uint32_t ncand = (vf.x != 0) + (vf.y != 0) + (vr.x != 0) + (vr.y != 0);
-            if (ncand) {
-                uint32_t o = atomicAdd(t.nwork, ncand);
-                const uint32_t mf = cur.rl | (0u << 8) | (cur.pw << 9), mr = cur.rl | (1u << 8) | (cur.pw << 9);
-                const uint32_t code[4] = {vf.x, vf.y, vr.x, vr.y};
-                const uint32_t meta[4] = {mf, mf, mr, mr};
-#pragma unroll
-                for (int k = 0; k < 4; k++)
-                    if (code[k]) {
-                        if (o < (uint32_t)kWorkCap) t.work[o] = make_uint2(code[k], meta[k]);
-                        else resolve<CAP>(ix, t, swp, code[k], meta[k]);
-                        o++;
-                    }
-            }
-            wave_sync();
-            const uint32_t nw = *(volatile uint32_t *)t.nwork;
-            if (nw >= (uint32_t)kWorkDrain) drain_work<CAP>(ix, t, swp, nw);
-            cur = nxt;
         }
-        {
-            wave_sync();
-            const uint32_t nw = *(volatile uint32_t *)t.nwork;
-            if (nw != 0) drain_work<CAP>(ix, t, swp, nw);
-        }
+        if (nw) drain_work<CAP>(ix, t, swp, nw);
         wave_sync();
 
         // ---- decision phase: one lane per read
