@@ -1,0 +1,301 @@
+// cammiq_main.cpp -- `cammiq --query ...` command-line shell on top of libcammiq_hip.so.
+//
+// Keeps the query-side contract of the reference CLI (/root/reference/src/main.cpp:74-446,
+// README "Query" section): same flags, same stderr lines, same --read_cnts TSV
+// (FqReader::outputUniqueCnts, /root/reference/src/query.cpp:1786-1818), while the classify
+// step runs on the GPU through the C ABI.  Own code: a thin restatement of the driver
+// (FqReader::loadSmap query.cpp:125-156, readFastq :371-425, queryFastq_p/_sc :231-369),
+// not a port of it.  Out of scope here, exactly as in BASELINE.json's north star:
+//   --build        index construction stays with the reference's own binary;
+//   the ILP        runILP_* needs CPLEX/Gurobi; with --dump_counts FILE this shell writes
+//                  everything the unmodified ILP consumes (per-genome counts, per-leaf rcount
+//                  in map_sp order) so a host with a solver can pick it up.
+// Extensions (not in the reference): --device N, --dump_counts FILE, missing .bin2 allowed.
+#include <dirent.h>
+#include <sys/stat.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <set>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "../../include/cammiq_hip.h"
+
+namespace {
+
+struct Genome { uint32_t taxID; std::string name; };
+
+bool valid_file(const char *p) { struct stat st; return stat(p, &st) == 0; }
+
+std::string ext_of(const std::string &f) { return f.substr(f.find_last_of('.') + 1); }
+
+std::string base_name(const std::string &p)
+{
+    size_t k = p.find_last_of('/');
+    return k == std::string::npos ? p : p.substr(k + 1);
+}
+
+[[noreturn]] void die(const char *fmt, const char *arg = nullptr)
+{
+    if (arg) fprintf(stderr, fmt, arg); else fputs(fmt, stderr);
+    exit(EXIT_FAILURE);
+}
+
+// FqReader::loadSmap (query.cpp:125-156): genomes[] is filled in map-file LINE ORDER and
+// indexed by refID; a repeated taxID appends the name to an existing entry.
+std::vector<Genome> load_map(const std::string &fn)
+{
+    std::vector<Genome> g(1);
+    std::ifstream in(fn);
+    if (!in.is_open()) die("Can not open map file %s.\n", fn.c_str());
+    std::string line;
+    std::set<uint32_t> taxids;
+    while (std::getline(in, line)) {
+        std::istringstream ls(line);
+        std::string file, id, taxid, name;
+        std::getline(ls, file, '\t'); std::getline(ls, id, '\t'); std::getline(ls, taxid, '\t'); std::getline(ls, name, '\t');
+        if (id.empty() || taxid.empty()) continue;
+        uint32_t t = (uint32_t)atoi(taxid.c_str());
+        if (taxids.count(t)) {
+            size_t i = (size_t)atoi(id.c_str());
+            if (i < g.size()) g[i].name += "/" + name;
+        } else {
+            g.push_back(Genome{t, name});
+            taxids.insert(t);
+        }
+    }
+    fprintf(stderr, "Loaded genome map file.\n");
+    return g;
+}
+
+// FqReader::readFastq (query.cpp:371-425): second line of every four; reads shorter than
+// min_l are dropped; every 'N' of a read is replaced by ONE random base per read.  The
+// reference seeds rand() from the clock, so its output on reads with N is not reproducible;
+// this shell uses a fixed-seed generator instead (documented deviation).
+void read_fastq(const std::string &fn, size_t min_l, std::vector<uint8_t> &bases, std::vector<uint64_t> &offs)
+{
+    std::ifstream in(fn);
+    if (!in.is_open()) die("Failed to find input file %s.\n", fn.c_str());
+    bases.clear(); offs.assign(1, 0);
+    std::string l;
+    uint64_t lcg = 0x9E3779B97F4A7C15ull;
+    const char alphabet[4] = {'A', 'C', 'G', 'T'};
+    while (std::getline(in, l)) {
+        if (!std::getline(in, l)) break;
+        if (!l.empty() && l.back() == '\r') l.pop_back();
+        if (l.size() >= min_l) {
+            lcg = lcg * 6364136223846793005ull + 1442695040888963407ull;
+            const char sub = alphabet[(lcg >> 60) & 3];
+            for (char &c : l) if (c == 'N') c = sub;
+            bases.insert(bases.end(), l.begin(), l.end());
+            offs.push_back(bases.size());
+        }
+        std::string skip;
+        std::getline(in, skip); std::getline(in, skip);
+    }
+    fprintf(stderr, "Loaded query file %s.\n", fn.c_str());
+}
+
+void list_fastq(const std::string &dir, std::vector<std::string> &out)
+{
+    DIR *d = opendir(dir.c_str());
+    if (!d) die("Input directory not exists.\n");
+    while (dirent *e = readdir(d)) {
+        std::string f = e->d_name;
+        if (f.size() >= 7) {
+            std::string x = ext_of(f);
+            if (x == "fq" || x == "fastq") out.push_back(dir + f);
+        }
+    }
+    closedir(d);
+}
+
+}  // namespace
+
+int main(int argc, char **argv)
+{
+    int mode = -1, id_mode = 0, t = 1, h = -1, h1 = -1, h2 = -1, device = 0;
+    size_t min_rl = 0;
+    std::string fi1, fi2, fm, output = "CAMMiQ_output.txt", fq_dir, dump;
+    std::vector<std::string> fq_names;
+    float erate = 0.01f;
+    auto need = [&](int &i, const char *msg) { if (++i >= argc) die(msg); return argv[i]; };
+
+    for (int i = 1; i < argc; i++) {
+        std::string v(argv[i]);
+        if (v == "--build") { mode = 0; continue; }
+        if (v == "--query") { mode = 1; continue; }
+        if (v == "--read_cnts") {
+            if (mode <= 0) die("Option --read_cnts is only valid in mode QUERY.\n");
+            id_mode = 1; continue;
+        }
+        if (v == "--doubly_unique") {
+            if (mode == 0) continue;
+            if (id_mode == 0) die("Option --doubly_unique is only valid in --read_cnts queries.\n");
+            id_mode = 2; continue;
+        }
+        if (v == "--unique" || v == "--both") {
+            if (mode > 0) die("Option --unique is only valid in mode BUILD.\n");
+            continue;
+        }
+        if (v == "--enable_ilp_display") { if (mode <= 0) die("Option --enable_ilp_display is only valid in mode QUERY.\n"); continue; }
+        if (v == "--read_length_filter") {
+            if (mode <= 0) die("Option --read_length_filter is only valid in mode QUERY.\n");
+            min_rl = (size_t)atoi(need(i, "Please specify a parameter value for --read_length_filter.\n")); continue;
+        }
+        if (v == "--read_cnt_thres" || v == "--easy_to_identify_thres" || v == "--unique_read_cnt_thres" ||
+            v == "--doubly_unique_read_cnt_thres" || v == "--ilp_alpha" || v == "--ilp_epsilon" || v == "--ilp_max_cov" ||
+            v == "--ilp_resolution") {   // fine parameters feed the ILP only (main.cpp:141-222)
+            need(i, "Please specify a parameter value.\n"); continue;
+        }
+        if (v == "--device") { device = atoi(need(i, "Please specify the GPU ordinal.\n")); continue; }
+        if (v == "--dump_counts") { dump = need(i, "Please specify the counts file name.\n"); continue; }
+        if (v == "-h") {
+            need(i, "Please specify the hash length.\n");
+            if (i + 1 < argc && argv[i + 1][0] != '-') { h1 = atoi(argv[i++]); h2 = atoi(argv[i]); }
+            else h = atoi(argv[i]);
+            for (int x : {h, h1, h2})
+                if (x != -1 && (x <= 4 || x >= 32)) die("The hash length should be in range [5, 31].\n");
+            continue;
+        }
+        if (v == "-i") {
+            if (++i >= argc) die("Please specify index file names.\n");
+            while (i < argc && argv[i][0] != '-') {
+                std::string f = argv[i++], x = ext_of(f);
+                if (x == "idx1" || x == "bin1") fi1 = f;
+                if (x == "idx2" || x == "bin2") fi2 = f;
+            }
+            i--; continue;
+        }
+        if (v == "-o") { if (mode <= 0) die("Parameter o is only valid in mode QUERY.\n"); output = need(i, "Please specify the output file name.\n"); continue; }
+        if (v == "-e") { erate = (float)atof(need(i, "Please specify the error rate.\n")); continue; }
+        if (v == "-t") { t = atoi(need(i, "Please specify the worker threads number.\n")); continue; }
+        if (v == "-f") {
+            if (++i >= argc) die("Please specify file names.\n");
+            while (i < argc && argv[i][0] != '-') {
+                std::string f = argv[i++], x = ext_of(f);
+                if (x == "out" || x == "map") fm = f;
+            }
+            i--; continue;
+        }
+        if (v == "-q") {
+            if (++i >= argc) die("Please specify query file names.\n");
+            while (i < argc && argv[i][0] != '-') {
+                std::string f = argv[i++], x = ext_of(f);
+                if (x == "fq" || x == "fastq") {
+                    if (!valid_file(f.c_str())) die("Failed to find input file %s.\n", f.c_str());
+                    fq_names.push_back(f);
+                }
+            }
+            i--; continue;
+        }
+        if (v == "-Q") {
+            fq_dir = need(i, "Please specify the directory containing fastq files.\n");
+            if (!valid_file(fq_dir.c_str())) die("Failed to find input directory %s.\n", fq_dir.c_str());
+            continue;
+        }
+        if (v == "-k" || v == "-L" || v == "-Lmax" || v == "-D") { need(i, "Please specify a value.\n"); continue; }   // build-side
+        fprintf(stderr, "Failed to recognize option: %s. \n", v.c_str());
+        return EXIT_FAILURE;
+    }
+    (void)erate; (void)t;
+    if (mode == 0) die("cammiq (MI355X query engine): index construction is out of scope; build the index with the "
+                       "reference CAMMiQ and query it here.\n");
+    if (mode != 1) die("Please specify --query.\n");
+    if (fi1.empty()) die("Please specify index file names.\n");
+    if (fm.empty()) die("Please specify file names.\n");
+    if (fq_names.empty()) {
+        if (fq_dir.empty()) die("Please specify at least one query file or directory.\n");
+        list_fastq(fq_dir, fq_names);
+    }
+
+    auto t0 = std::chrono::high_resolution_clock::now();
+    cq_index *ix = nullptr;
+    if (cq_index_load(fi1.c_str(), fi2.empty() ? nullptr : fi2.c_str(), device, &ix) != CQ_OK) {
+        fprintf(stderr, "%s\n", cq_last_error());
+        return EXIT_FAILURE;
+    }
+    cq_index_info info;
+    cq_index_get_info(ix, &info);
+    fprintf(stderr, "Index: %s\nHash Length: %u\n", fi1.c_str(), info.hash_len);
+    if (!fi2.empty()) fprintf(stderr, "Index: %s\nHash Length: %u\n", fi2.c_str(), info.hash_len);
+    for (int x : {h, h1, h2})
+        if (x != -1 && (uint32_t)x != info.hash_len) die("Hash length given with -h differs from the one encoded in the index.\n");
+    fprintf(stderr, "Loaded index files into memory.\n");
+    fprintf(stderr, "Time for loading index: %lu ms.\n",
+            (unsigned long)std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::high_resolution_clock::now() - t0).count());
+
+    std::vector<Genome> genomes = load_map(fm);
+    const uint32_t G = (uint32_t)genomes.size() - 1;
+    std::vector<cq_leaf> leaves[2];
+    for (int tb = 0; tb < 2; tb++) {
+        leaves[tb].resize(info.n_leaves[tb]);
+        cq_index_leaves(ix, tb, leaves[tb].data());
+    }
+
+    std::vector<uint8_t> bases;
+    std::vector<uint64_t> offs;
+    std::vector<uint64_t> cu(G + 1), cd(G + 1), pc(1 << 16);
+    std::vector<uint32_t> ru(info.n_leaves[0]), rd(info.n_leaves[1]), pa(1 << 16), pb(1 << 16);
+    for (size_t f = 0; f < fq_names.size(); f++) {
+        read_fastq(fq_names[f], min_rl, bases, offs);
+        const std::string cur = base_name(fq_names[f]);
+        if (id_mode && t > 1) fprintf(stderr, "Single cell queries only support one thread.\n");
+        fprintf(stderr, "Querying %s.\n", cur.c_str());
+        auto q0 = std::chrono::high_resolution_clock::now();
+        cq_counts c;
+        memset(&c, 0, sizeof c);
+        c.cnt_u = cu.data(); c.cnt_d = cd.data();
+        c.rcount_u = ru.empty() ? nullptr : ru.data(); c.rcount_d = rd.empty() ? nullptr : rd.data();
+        c.pair_a = pa.data(); c.pair_b = pb.data(); c.pair_cnt = pc.data(); c.pair_cap = pc.size();
+        int rc = cq_query(ix, id_mode ? CQ_MODE_SC : CQ_MODE_P, bases.data(), offs.data(), offs.size() - 1, G, &c);
+        if (rc != CQ_OK) { fprintf(stderr, "%s\n", cq_last_error()); return EXIT_FAILURE; }
+        fprintf(stderr, "Processed %lu reads.\r", (unsigned long)(offs.size() - 1));
+        fprintf(stderr, "\nNumber of unlabeled reads: %lu.\n", (unsigned long)c.nundet);
+        fprintf(stderr, "Number of reads with conflict labels: %lu.\n", (unsigned long)c.nconf);
+        if (c.nskipped) fprintf(stderr, "Number of reads outside the supported domain (skipped): %lu.\n", (unsigned long)c.nskipped);
+        fprintf(stderr, "Completed query %s.\n", cur.c_str());
+        fprintf(stderr, "Time for query: %lu ms.\n",
+                (unsigned long)std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::high_resolution_clock::now() - q0).count());
+
+        if (id_mode == 1) {   // outputUniqueCnts, query.cpp:1786-1818
+            FILE *fo = fopen(output.c_str(), f == 0 ? "w" : "a");
+            if (!fo) die("Can not open output file %s.\n", output.c_str());
+            if (f == 0) {
+                fprintf(fo, "QUERY/TAXID\t");
+                for (uint32_t i = 1; i <= G; i++) fprintf(fo, i < G ? "%u\t" : "%u\n", genomes[i].taxID);
+            }
+            fprintf(fo, "%s\t", cur.c_str());
+            for (uint32_t i = 1; i <= G; i++) fprintf(fo, i < G ? "%lu\t" : "%lu\n", (unsigned long)cu[i]);
+            fclose(fo);
+        }
+        if (!dump.empty()) {
+            // Everything runILP_* reads from FqReader state (query.cpp:1157-1226): per-genome
+            // counts, and per genome g the rcount of every leaf of map_sp[g] in decode order.
+            FILE *fo = fopen(dump.c_str(), f == 0 ? "w" : "a");
+            if (!fo) die("Can not open output file %s.\n", dump.c_str());
+            fprintf(fo, "#query\t%s\tnundet\t%lu\tnconf\t%lu\n", cur.c_str(), (unsigned long)c.nundet, (unsigned long)c.nconf);
+            for (uint32_t g = 1; g <= G; g++)
+                fprintf(fo, "G\t%u\t%u\t%lu\t%lu\n", g, genomes[g].taxID, (unsigned long)cu[g], (unsigned long)cd[g]);
+            if (!id_mode)
+                for (int tb = 0; tb < 2; tb++)
+                    for (size_t i = 0; i < leaves[tb].size(); i++) {
+                        const uint32_t r = tb ? rd[i] : ru[i];
+                        if (r) fprintf(fo, "L\t%c\t%zu\t%u\t%u\t%u\t%u\n", tb ? 'd' : 'u', i, leaves[tb][i].refID1,
+                                       leaves[tb][i].refID2, (unsigned)leaves[tb][i].depth, r);
+                    }
+            for (uint64_t i = 0; i < c.n_pairs; i++)
+                fprintf(fo, "P\t%u\t%u\t%lu\n", pa[i], pb[i], (unsigned long)pc[i]);
+            fclose(fo);
+        }
+    }
+    cq_index_free(ix);
+    return 0;
+}

@@ -8,6 +8,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <thread>
@@ -147,7 +148,10 @@ int cq_index_load(const char *path_u, const char *path_d, int device, cq_index *
             ix->doubly_flag[t] = ix->tab[t].doubly;
         }
         std::string err;
-        int rc = cq::build_image(ix->tab[0], ix->tab[1], 1.5, ix->img, err);
+        // tuning knob (not part of the ABI): average keys per 4-slot bucket of the device table
+        double kpb = 1.5;
+        if (const char *e = getenv("CAMMIQ_KEYS_PER_BUCKET")) kpb = atof(e);
+        int rc = cq::build_image(ix->tab[0], ix->tab[1], kpb, ix->img, err);
         if (rc != CQ_OK) { delete ix; return fail(rc, err); }
         // bucket/node arrays of the decode stage are no longer needed; leaves are (cq_index_leaves)
         for (int t = 0; t < 2; t++) {
