@@ -49,7 +49,7 @@ def main():
     ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU per step")
     ap.add_argument("--read-len", type=int, default=100)
     ap.add_argument("--both", action="store_true", help="unique + doubly-unique index (configs[2] shape)")
-    ap.add_argument("--cpu-sample", type=int, default=200_000, help="reads timed through the CPU oracle (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=2_000_000, help="reads timed through the CPU oracle (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
