@@ -76,13 +76,22 @@ def main():
     G = args.genomes
     tables = 2 if args.both else 1
     t_setup = time.time()
-    wdir = tempfile.mkdtemp(prefix=f"cammiq_bench_r{rank}_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    # one copy of the index files per node: local rank 0 writes, the others wait
+    shm = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
+    wdir = os.path.join(shm, f"cammiq_bench_{os.environ.get('MASTER_PORT', os.getpid())}")
     try:
         w = bigsynth.World(seed=2, n_genomes=G, genome_len=args.genome_len, k=k, h=h, lmax=50,
                            pair_share=0.3 if args.both else 0.0)
         pu = os.path.join(wdir, "index_u.bin1")
         pd = os.path.join(wdir, "index_d.bin2") if args.both else None
-        nu, nd = w.write_index(pu, pd)
+        if local_rank == 0:
+            os.makedirs(wdir, exist_ok=True)
+            nu, nd = w.write_index(pu, pd)
+            with open(os.path.join(wdir, "leaves.txt"), "w") as f:
+                f.write(f"{nu} {nd}\n")
+        if world > 1:
+            tdist.barrier()
+        nu, nd = (int(x) for x in open(os.path.join(wdir, "leaves.txt")).read().split())
         t_gen = time.time() - t_setup
         t0 = time.time()
         ix = cq.Index(pu, pd, device=local_rank)
@@ -207,7 +216,10 @@ def main():
         if rank == 0:
             print(json.dumps(result), flush=True)
     finally:
-        shutil.rmtree(wdir, ignore_errors=True)
+        if world > 1:
+            tdist.barrier()
+        if local_rank == 0:
+            shutil.rmtree(wdir, ignore_errors=True)
         if world > 1:
             tdist.destroy_process_group()
 

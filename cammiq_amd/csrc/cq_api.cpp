@@ -9,6 +9,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <string>
 #include <thread>
@@ -148,8 +149,19 @@ int cq_index_load(const char *path_u, const char *path_d, int device, cq_index *
             ix->doubly_flag[t] = ix->tab[t].doubly;
         }
         std::string err;
-        // tuning knob (not part of the ABI): average keys per 4-slot bucket of the device table
-        double kpb = 1.5;
+        // Average keys per 4-slot bucket of the device table.  Emptier tables overflow less
+        // (fewer windows take the exact path): 0.75 costs 85 B of HBM per key and is 20 % faster
+        // than 1.5; when the table would not fit comfortably it is packed tighter.
+        // CAMMIQ_KEYS_PER_BUCKET overrides (tuning knob, not part of the ABI).
+        double kpb = 0.75;
+        if (device >= 0) {
+            size_t free_b = 0, total_b = 0;
+            if (hipSetDevice(device) == hipSuccess && hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b) {
+                const double keys = (double)(ix->tab[0].bucket_key.size() + ix->tab[1].bucket_key.size());
+                const double budget = 0.5 * (double)free_b;
+                if (keys / kpb * 64.0 > budget) kpb = std::min(3.2, keys * 64.0 / budget);
+            }
+        }
         if (const char *e = getenv("CAMMIQ_KEYS_PER_BUCKET")) kpb = atof(e);
         int rc = cq::build_image(ix->tab[0], ix->tab[1], kpb, ix->img, err);
         if (rc != CQ_OK) { delete ix; return fail(rc, err); }

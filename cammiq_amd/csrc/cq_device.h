@@ -54,12 +54,13 @@ CQ_HD uint64_t cq_rev2(uint64_t x)
 /* Reverse complement of the h-symbol string in the low 2h bits of x (A<->T, C<->G = 3-s). */
 CQ_HD uint64_t cq_revcomp(uint64_t x, uint32_t h) { return (~cq_rev2(x)) >> (64u - 2u * h); }
 
-/* Bijection on 32 bits (odd multiplies + xorshifts): equal phi <=> equal m-mer, so the
- * minimum is unambiguous and identical for a key and its reverse complement. */
+/* Bijection on 32 bits (odd multiply + xorshift): equal phi <=> equal m-mer, so the minimum
+ * is unambiguous and identical for a key and its reverse complement.  One multiply only:
+ * 32-bit integer multiplies are quarter rate on CDNA and this runs once per base. */
 CQ_HD uint32_t cq_phi32(uint32_t c)
 {
-    c *= 0x9E3779B1u; c ^= c >> 15;
-    c *= 0x85EBCA6Bu; c ^= c >> 13;
+    c *= 0x9E3779B1u;
+    c ^= c >> 15;
     return c;
 }
 
@@ -106,11 +107,10 @@ CQ_HD uint32_t cq_hash32(uint64_t k)
 
 CQ_HD uint32_t cq_bucket_of_minimizer(uint32_t min_phi, uint32_t n_buckets)
 {
-    uint32_t x = (min_phi ^ 0x5BD1E995u) * 0xC2B2AE35u;
-    x ^= x >> 15; x *= 0x27D4EB2Fu;
-    x ^= x >> 13; x *= 0x165667B1u;
-    x ^= x >> 16;
-    return (uint32_t)(((uint64_t)x * (uint64_t)n_buckets) >> 32);
+    /* min_phi is already a mixed value, only biased towards small numbers (it is a minimum):
+     * one more odd multiply spreads it over the high bits the range reduction uses. */
+    const uint32_t x = (min_phi ^ 0x5BD1E995u) * 0x85EBCA6Bu;
+    return (uint32_t)(((uint64_t)(x ^ (x >> 16)) * (uint64_t)n_buckets) >> 32);
 }
 
 /* Home bucket of an h-mer key (host side; the kernel has fw and rc at hand already). */

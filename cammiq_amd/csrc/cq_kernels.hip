@@ -41,8 +41,11 @@ namespace {
 
 constexpr int kBlock = 256;
 constexpr int kWaves = kBlock / 64;
-constexpr int kWorkDrain = 64;   // drain a wave's list once it can fill the wave
-constexpr int kWorkCap = 128;    // an iteration appends at most one item per lane: 63 + 64 < 128
+#ifndef CQ_WORK_DRAIN
+#define CQ_WORK_DRAIN 64
+#endif
+constexpr int kWorkDrain = CQ_WORK_DRAIN;     // drain a wave's list once it holds this many items
+constexpr int kWorkCap = kWorkDrain + 64;     // an iteration appends at most one item per lane
 
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 
@@ -130,10 +133,11 @@ struct Tile {             // one wave's view of LDS
     uint32_t *scal;      // [4] nundet nconf nskipped nslow   (workgroup-shared)
 };
 
-// floor(idx / d) for idx < 2^16, d < 2^8 with magic = ceil(2^32 / d) (exact in that range).
+// floor(idx / d) for idx < 2^11, d < 2^8 with magic = ceil(2^19 / d): exact in that range, and
+// a 24-bit multiply (full rate) instead of a 32-bit multiply-high (quarter rate).
 __device__ __forceinline__ uint32_t div_small(uint32_t idx, uint32_t d, uint32_t magic)
 {
-    return d == 1 ? idx : __umulhi(idx, magic);
+    return __umul24(idx, magic) >> 19;
 }
 
 // hashtrie.cpp:350-369 on the array trie.  `code` is the bucket root; returns the global
@@ -358,7 +362,7 @@ __global__ void __launch_bounds__(kBlock) classify_kernel(DevIndex ix, QueryArgs
             const uint32_t nvec = nr * (sw >> 2);
             for (uint32_t i = lane; i < nvec; i += 64) {
                 const uint4 v = src[i];
-                const uint32_t w = i * 4, rl = w / sw, c = w - rl * sw;
+                const uint32_t w = i * 4, rl = div_small(w, sw, a.magic_s), c = w - __umul24(rl, sw);
                 uint32_t *dst = t.rows + rl * swp + c;
                 dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
             }
@@ -381,12 +385,13 @@ __global__ void __launch_bounds__(kBlock) classify_kernel(DevIndex ix, QueryArgs
         {
             const uint32_t total = nr * pmax;
             for (uint32_t idx = lane; idx < total; idx += 64) {
-                const uint32_t rl = div_small(idx, pmax, a.magic_p), j = idx - rl * pmax;
+                const uint32_t rl = div_small(idx, pmax, a.magic_p), j = idx - __umul24(rl, pmax);
                 if (j + m <= t.len[rl]) {
-                    const uint32_t *row = t.rows + rl * swp;
+                    const uint32_t *row = t.rows + __umul24(rl, swp);
                     const uint32_t q = j >> 4, s = (j & 15u) * 2u;
-                    const uint64_t x = ((uint64_t)row[q] << 32) | row[q + 1];
-                    t.phi[idx] = cq_mmer_phi((uint32_t)(x >> (64u - s - 2u * m)) & mmask, m);
+                    // the 32 bits that start at base j, then keep the first m bases of them
+                    const uint32_t w32 = __funnelshift_l(row[q + 1], row[q], s);
+                    t.phi[idx] = cq_mmer_phi((w32 >> (32u - 2u * m)) & mmask, m);
                 }
             }
         }
@@ -409,20 +414,20 @@ __global__ void __launch_bounds__(kBlock) classify_kernel(DevIndex ix, QueryArgs
             bool flag = false;
             if (act) {
                 rl = div_small(idx, wmax, a.magic_w);
-                pw = idx - rl * wmax;
+                pw = idx - __umul24(rl, wmax);
                 const uint32_t len = t.len[rl];
                 act = (len >= h) && (pw + h <= len);
             }
             if (act) {
                 // minimizer hash = min over the h-m+1 m-mers of the window
-                const uint32_t *ph = t.phi + rl * pmax + pw;
+                const uint32_t *ph = t.phi + __umul24(rl, pmax) + pw;
                 uint32_t mp = ph[0];
                 for (uint32_t i = 1; i < nphi; i++) mp = min(mp, ph[i]);
                 b = cq_bucket_of_minimizer(mp, ix.n_buckets);
                 const Bucket bk = load_bucket(ix.slots, b);
                 // low word of the forward h-mer: the 32 bits that END at the window's end;
                 // low word of the reverse complement: ~reverse of the 32 bits that START it
-                const uint32_t *row = t.rows + rl * swp;
+                const uint32_t *row = t.rows + __umul24(rl, swp);
                 const uint32_t e = pw + h;                       // one past the last base
                 const uint32_t qe = e >> 4, se = (e & 15u) * 2u; // bit offset of the end in word qe
                 const uint32_t tail = qe ? (se ? __funnelshift_l(row[qe], row[qe - 1], se) : row[qe - 1])
@@ -484,7 +489,10 @@ __global__ void __launch_bounds__(kBlock) classify_kernel(DevIndex ix, QueryArgs
     }
 }
 
-constexpr int kFastR = 8, kFastCAP = 16;
+#ifndef CQ_FAST_R
+#define CQ_FAST_R 8
+#endif
+constexpr int kFastR = CQ_FAST_R, kFastCAP = 16;
 constexpr int kSlowR = 1, kSlowCAP = 1024;
 
 static size_t smem_bytes(int R, int CAP, const QueryArgs &a, bool hist)
@@ -497,7 +505,7 @@ bool lds_hist_fits(uint32_t n_genomes)
     return 2 * ((size_t)n_genomes + 1) * 4 <= 32 * 1024;
 }
 
-static uint32_t magic_of(uint32_t d) { return d <= 1 ? 0u : (uint32_t)((0x100000000ull + d - 1) / d); }
+static uint32_t magic_of(uint32_t d) { return d == 0 ? 0u : (uint32_t)(((1u << 19) + d - 1) / d); }
 
 hipError_t launch_classify(const DevIndex &ix, QueryArgs a, int n_cus, hipStream_t stream,
                            hipEvent_t ev_start, hipEvent_t ev_stop)
@@ -506,6 +514,7 @@ hipError_t launch_classify(const DevIndex &ix, QueryArgs a, int n_cus, hipStream
     a.pmax = a.wmax + (ix.hash_len - ix.minimizer_len);   // m-mer positions: max_len - m + 1
     a.magic_w = magic_of(a.wmax);
     a.magic_p = magic_of(a.pmax);
+    a.magic_s = magic_of(a.stride_words);
     hipError_t e;
     // LDS above the 64 KiB default needs an explicit opt-in (large G)
     e = hipFuncSetAttribute((const void *)classify_kernel<kFastR, kFastCAP, false>,
