@@ -185,6 +185,18 @@ def main():
                             "pack_reads": round(t_pack, 2)},
             }
 
+        # ---- PCIe-inclusive rate of the host-buffer API (never `value`): ASCII reads in host
+        #      memory -> pack -> H2D -> kernel -> D2H, chunks pipelined inside cq_query
+        if rank == 0 and world == 1:
+            ix.query(bases[:args.read_len * 1000], offs[:1001], G)          # warm the staging buffers
+            t0 = time.perf_counter()
+            hq = ix.query(bases, offs, G)
+            th = time.perf_counter() - t0
+            result["host_api"] = {"Mreads_s": round(n / th / 1e6, 2), "seconds": round(th, 4),
+                                  "what": "cq_query on ASCII reads in pageable host memory, counters back on the host "
+                                          "(pack + H2D + kernel + D2H, 2 M-read chunks double-buffered)"}
+            assert int(hq["cnt_u"].sum()) == cnt_u_sum and hq["nundet"] == nundet, "host API disagrees with device API"
+
         # ---- CPU baseline (rank 0, N = 1 only): the oracle, a restatement of query64mt_p
         if rank == 0 and world == 1 and not args.no_cpu_baseline and args.cpu_sample > 0:
             sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -58,6 +58,17 @@ struct cq_index {
     uint64_t *d_pair_keys = nullptr, *d_pair_cnts = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool ev_valid = false;
+    // host-buffer path (cq_query): two staging slots so that packing chunk c+1 on the CPU, its
+    // H2D copy and the classify kernel of chunk c overlap
+    struct Slot {
+        uint32_t *h_packed = nullptr, *d_packed = nullptr;   // pinned host / device rows
+        uint8_t *h_lens = nullptr, *d_lens = nullptr;
+        size_t cap_words = 0, cap_reads = 0;
+        hipEvent_t copied = nullptr, done = nullptr;
+    } slot[2];
+    hipStream_t s_copy = nullptr, s_comp = nullptr;
+    uint64_t *d_ctr = nullptr; size_t ctr_cap = 0;
+    uint32_t *d_rc = nullptr; size_t rc_cap = 0;
 };
 
 namespace {
@@ -75,6 +86,18 @@ void release_device(cq_index *ix)
     if (ix->d_pair_cnts) (void)hipFree(ix->d_pair_cnts);
     if (ix->ev0) (void)hipEventDestroy(ix->ev0);
     if (ix->ev1) (void)hipEventDestroy(ix->ev1);
+    for (auto &sl : ix->slot) {
+        if (sl.h_packed) (void)hipHostFree(sl.h_packed);
+        if (sl.h_lens) (void)hipHostFree(sl.h_lens);
+        if (sl.d_packed) (void)hipFree(sl.d_packed);
+        if (sl.d_lens) (void)hipFree(sl.d_lens);
+        if (sl.copied) (void)hipEventDestroy(sl.copied);
+        if (sl.done) (void)hipEventDestroy(sl.done);
+    }
+    if (ix->s_copy) (void)hipStreamDestroy(ix->s_copy);
+    if (ix->s_comp) (void)hipStreamDestroy(ix->s_comp);
+    if (ix->d_ctr) (void)hipFree(ix->d_ctr);
+    if (ix->d_rc) (void)hipFree(ix->d_rc);
 }
 
 int upload(cq_index *ix)
@@ -313,95 +336,117 @@ int cq_pairs_fetch(cq_index *ix, uint32_t *pair_a, uint32_t *pair_b, uint64_t *p
     return CQ_OK;
 }
 
+namespace {
+
+// Grow one staging slot to hold n reads of sw words.
+int slot_reserve(cq_index::Slot &sl, uint64_t n, uint32_t sw)
+{
+    const size_t words = (size_t)n * sw;
+    if (sl.cap_words < words) {
+        if (sl.h_packed) (void)hipHostFree(sl.h_packed);
+        if (sl.d_packed) (void)hipFree(sl.d_packed);
+        sl.h_packed = nullptr; sl.d_packed = nullptr; sl.cap_words = 0;
+        CQ_HIP(hipHostMalloc((void **)&sl.h_packed, words * 4, hipHostMallocDefault));
+        CQ_HIP(hipMalloc((void **)&sl.d_packed, words * 4));
+        sl.cap_words = words;
+    }
+    if (sl.cap_reads < n) {
+        if (sl.h_lens) (void)hipHostFree(sl.h_lens);
+        if (sl.d_lens) (void)hipFree(sl.d_lens);
+        sl.h_lens = nullptr; sl.d_lens = nullptr; sl.cap_reads = 0;
+        CQ_HIP(hipHostMalloc((void **)&sl.h_lens, n, hipHostMallocDefault));
+        CQ_HIP(hipMalloc((void **)&sl.d_lens, n));
+        sl.cap_reads = n;
+    }
+    if (!sl.copied) CQ_HIP(hipEventCreateWithFlags(&sl.copied, hipEventDisableTiming));
+    if (!sl.done) CQ_HIP(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+    return CQ_OK;
+}
+
+}  // namespace
+
 int cq_query(cq_index *ix, int mode, const uint8_t *bases, const uint64_t *offsets,
              uint64_t n_reads, uint32_t n_genomes, cq_counts *out)
 {
     if (!ix || !out || !offsets) return fail(CQ_ERR_ARG, "cq_query: NULL argument");
     if (!out->cnt_u || !out->cnt_d) return fail(CQ_ERR_ARG, "cq_query: cnt_u / cnt_d must be provided");
-    if (mode == CQ_MODE_P && (!out->rcount_u || !out->rcount_d) &&
-        (ix->img.n_leaves[0] + ix->img.n_leaves[1]) != 0 && !(out->rcount_u == nullptr && ix->img.n_leaves[0] == 0) &&
-        !(out->rcount_d == nullptr && ix->img.n_leaves[1] == 0))
+    if (mode == CQ_MODE_P && ((!out->rcount_u && ix->img.n_leaves[0]) || (!out->rcount_d && ix->img.n_leaves[1])))
         return fail(CQ_ERR_ARG, "cq_query: rcount_u / rcount_d are mandatory in CQ_MODE_P (the ILP reads them)");
     if (ix->device < 0) return fail(CQ_ERR_NO_DEVICE, "index was loaded host-only (CQ_DEVICE_NONE); no CPU classify path exists");
     if (ix->img.max_refid > n_genomes)
         return fail(CQ_ERR_RANGE, "index holds refID " + std::to_string(ix->img.max_refid) + " > n_genomes");
     CQ_HIP(hipSetDevice(ix->device));
+    if (!ix->s_copy) CQ_HIP(hipStreamCreateWithFlags(&ix->s_copy, hipStreamNonBlocking));
+    if (!ix->s_comp) CQ_HIP(hipStreamCreateWithFlags(&ix->s_comp, hipStreamNonBlocking));
 
     const uint64_t G1 = (uint64_t)n_genomes + 1, cw = cq_counter_words(n_genomes);
     const uint64_t nl = ix->img.n_leaves[0] + ix->img.n_leaves[1];
-    uint64_t *d_ctr = nullptr;
-    uint32_t *d_rc = nullptr;
-    CQ_HIP(hipMalloc((void **)&d_ctr, cw * 8));
-    CQ_HIP(hipMemset(d_ctr, 0, cw * 8));
-    if (mode == CQ_MODE_P && nl) {
-        CQ_HIP(hipMalloc((void **)&d_rc, nl * 4));
-        CQ_HIP(hipMemset(d_rc, 0, nl * 4));
+    if (ix->ctr_cap < cw) {
+        if (ix->d_ctr) (void)hipFree(ix->d_ctr);
+        ix->d_ctr = nullptr; ix->ctr_cap = 0;
+        CQ_HIP(hipMalloc((void **)&ix->d_ctr, cw * 8));
+        ix->ctr_cap = cw;
     }
-    // One call = one FASTQ; long inputs go through in chunks so the staging buffers stay bounded.
-    const uint64_t kChunk = 1ull << 24;
-    uint64_t skipped_host = 0;
+    CQ_HIP(hipMemsetAsync(ix->d_ctr, 0, cw * 8, ix->s_comp));
+    uint32_t *d_rc = nullptr;
+    if (mode == CQ_MODE_P && nl) {
+        if (ix->rc_cap < nl) {
+            if (ix->d_rc) (void)hipFree(ix->d_rc);
+            ix->d_rc = nullptr; ix->rc_cap = 0;
+            CQ_HIP(hipMalloc((void **)&ix->d_rc, nl * 4));
+            ix->rc_cap = nl;
+        }
+        d_rc = ix->d_rc;
+        CQ_HIP(hipMemsetAsync(d_rc, 0, nl * 4, ix->s_comp));
+    }
+
+    // One call = one FASTQ.  Chunks of 2 M reads alternate between two staging slots:
+    //   CPU   pack(c+1) ........ pack(c+2) ........
+    //   copy           H2D(c+1) ...........H2D(c+2)
+    //   comp  kernel(c) ........ kernel(c+1) .......
+    const uint64_t kChunk = 1ull << 21;
     int rc = CQ_OK;
-    std::vector<uint32_t> packed;
-    std::vector<uint8_t> lens;
-    uint32_t *d_packed = nullptr;
-    uint8_t *d_lens = nullptr;
-    uint64_t d_cap_reads = 0;
-    uint32_t d_cap_sw = 0;
-    for (uint64_t c0 = 0; c0 < n_reads && rc == CQ_OK; c0 += kChunk) {
+    uint64_t c = 0;
+    for (uint64_t c0 = 0; c0 < n_reads && rc == CQ_OK; c0 += kChunk, c++) {
+        cq_index::Slot &sl = ix->slot[c & 1];
         const uint64_t n = std::min(kChunk, n_reads - c0);
         uint64_t max_len = 0;
         for (uint64_t r = c0; r < c0 + n; r++) {
-            uint64_t l = offsets[r + 1] - offsets[r];
+            const uint64_t l = offsets[r + 1] - offsets[r];
             if (l <= 255 && l > max_len) max_len = l;
         }
         const uint32_t sw = cq_pack_stride_words((uint32_t)max_len);
-        packed.resize(n * sw);
-        lens.resize(n);
+        if (sl.done) CQ_HIP(hipEventSynchronize(sl.done));      // the kernel that last used this slot
+        rc = slot_reserve(sl, n, sw);
+        if (rc != CQ_OK) break;
         uint64_t sk = 0;
-        rc = cq_pack_reads(bases, offsets + c0, n, ix->img.hash_len, sw, packed.data(), lens.data(), &sk);
+        rc = cq_pack_reads(bases, offsets + c0, n, ix->img.hash_len, sw, sl.h_packed, sl.h_lens, &sk);
         if (rc != CQ_OK) { fail(rc, "cq_pack_reads failed"); break; }
-        skipped_host += sk;
-        if (d_cap_reads < n || d_cap_sw < sw) {
-            if (d_packed) (void)hipFree(d_packed);
-            if (d_lens) (void)hipFree(d_lens);
-            d_packed = nullptr; d_lens = nullptr;
-            if (hipMalloc((void **)&d_packed, n * sw * 4) != hipSuccess || hipMalloc((void **)&d_lens, n) != hipSuccess) {
-                rc = fail(CQ_ERR_HIP, "hipMalloc of the read staging buffers failed");
-                break;
-            }
-            d_cap_reads = n; d_cap_sw = sw;
-        }
-        if (hipMemcpy(d_packed, packed.data(), n * sw * 4, hipMemcpyHostToDevice) != hipSuccess ||
-            hipMemcpy(d_lens, lens.data(), n, hipMemcpyHostToDevice) != hipSuccess) {
-            rc = fail(CQ_ERR_HIP, "hipMemcpy of reads to the device failed");
-            break;
-        }
-        rc = cq_query_device(ix, mode, d_packed, d_lens, n, sw, (uint32_t)max_len, n_genomes, d_ctr, d_rc, nullptr);
-        if (rc == CQ_OK && hipDeviceSynchronize() != hipSuccess) rc = fail(CQ_ERR_HIP, "classify kernel failed");
+        CQ_HIP(hipMemcpyAsync(sl.d_packed, sl.h_packed, (size_t)n * sw * 4, hipMemcpyHostToDevice, ix->s_copy));
+        CQ_HIP(hipMemcpyAsync(sl.d_lens, sl.h_lens, n, hipMemcpyHostToDevice, ix->s_copy));
+        CQ_HIP(hipEventRecord(sl.copied, ix->s_copy));
+        CQ_HIP(hipStreamWaitEvent(ix->s_comp, sl.copied, 0));
+        rc = cq_query_device(ix, mode, sl.d_packed, sl.d_lens, n, sw, (uint32_t)max_len, n_genomes, ix->d_ctr, d_rc,
+                             ix->s_comp);
+        if (rc != CQ_OK) break;
+        CQ_HIP(hipEventRecord(sl.done, ix->s_comp));
     }
-    std::vector<uint64_t> ctr(cw, 0);
-    if (rc == CQ_OK && hipMemcpy(ctr.data(), d_ctr, cw * 8, hipMemcpyDeviceToHost) != hipSuccess)
-        rc = fail(CQ_ERR_HIP, "hipMemcpy of counters failed");
-    if (rc == CQ_OK && d_rc) {
-        if (out->rcount_u && ix->img.n_leaves[0] &&
-            hipMemcpy(out->rcount_u, d_rc, ix->img.n_leaves[0] * 4, hipMemcpyDeviceToHost) != hipSuccess)
-            rc = fail(CQ_ERR_HIP, "hipMemcpy of rcount_u failed");
-        if (rc == CQ_OK && out->rcount_d && ix->img.n_leaves[1] &&
-            hipMemcpy(out->rcount_d, d_rc + ix->img.n_leaves[0], ix->img.n_leaves[1] * 4, hipMemcpyDeviceToHost) != hipSuccess)
-            rc = fail(CQ_ERR_HIP, "hipMemcpy of rcount_d failed");
-    }
-    if (d_packed) (void)hipFree(d_packed);
-    if (d_lens) (void)hipFree(d_lens);
-    if (d_ctr) (void)hipFree(d_ctr);
-    if (d_rc) (void)hipFree(d_rc);
+    if (hipStreamSynchronize(ix->s_comp) != hipSuccess && rc == CQ_OK) rc = fail(CQ_ERR_HIP, "classify kernel failed");
     if (rc != CQ_OK) return rc;
 
+    std::vector<uint64_t> ctr(cw, 0);
+    CQ_HIP(hipMemcpy(ctr.data(), ix->d_ctr, cw * 8, hipMemcpyDeviceToHost));
+    if (d_rc) {
+        if (ix->img.n_leaves[0])
+            CQ_HIP(hipMemcpy(out->rcount_u, d_rc, ix->img.n_leaves[0] * 4, hipMemcpyDeviceToHost));
+        if (ix->img.n_leaves[1])
+            CQ_HIP(hipMemcpy(out->rcount_d, d_rc + ix->img.n_leaves[0], ix->img.n_leaves[1] * 4, hipMemcpyDeviceToHost));
+    }
     memcpy(out->cnt_u, ctr.data(), G1 * 8);
     memcpy(out->cnt_d, ctr.data() + G1, G1 * 8);
     out->nundet = ctr[CQ_CTR_NUNDET(n_genomes)];
     out->nconf = ctr[CQ_CTR_NCONF(n_genomes)];
     out->nskipped = ctr[CQ_CTR_NSKIP(n_genomes)];
-    (void)skipped_host;  // == nskipped: the kernel counts rows whose length was zeroed by the packer
     out->n_pairs = 0;
     if (mode == CQ_MODE_SC) {
         if (ctr[CQ_CTR_FLAGS(n_genomes)] & 1ull) return fail(CQ_ERR_LIMIT, "device pair table full");
