@@ -30,9 +30,66 @@ struct SymTable {
 };
 const SymTable kSym;
 
+// Scalar row packer (reference for the fast path; also the fallback without BMI2).
+inline bool pack_row_scalar(const uint8_t *s, uint32_t len, uint32_t *row)
+{
+    uint32_t bad = 0;
+    for (uint32_t j = 0; j < len; j++) {
+        const uint32_t c = kSym.t[s[j]];
+        bad |= c;
+        row[j >> 4] |= (c & 3u) << (30u - 2u * (j & 15u));
+    }
+    return !(bad & 0x80u);
+}
+
+#if defined(__x86_64__)
+#include <immintrin.h>
+// Eight ASCII bases -> 16 bits (first base in the top two bits), 64 bits at a time:
+// (c >> 1) & 3 maps A,C,G,T (either case) to 0,1,3,2; x ^= x >> 1 turns that into 0,1,2,3;
+// byte swap + PEXT gathers the eight 2-bit fields.  `bad` collects bytes that are not ACGTacgt
+// (checked by rebuilding the upper-case letter from the code and comparing).
+__attribute__((target("bmi2"))) inline uint32_t pack8(uint64_t w, uint64_t &bad)
+{
+    const uint64_t K1 = 0x0101010101010101ull;
+    const uint64_t u = w & (0xDFull * K1);                  // fold to upper case
+    const uint64_t raw = (w >> 1) & (3 * K1);                // A0 C1 G3 T2
+    const uint64_t r0 = raw & K1, r1 = (raw >> 1) & K1, r01 = r0 & r1;
+    // expected letter: 'A' + {0, 2, 0x13, 6}[raw]  ('A' 0x41, 'C' 0x43, 'T' 0x54, 'G' 0x47)
+    const uint64_t add = (r0 << 1) + (r1 << 4) + (r1 << 1) + r1 - (r01 << 4) + r01;
+    bad |= (0x41 * K1 + add) ^ u;
+    const uint64_t code = raw ^ r1;                          // A0 C1 G2 T3
+    return (uint32_t)_pext_u64(__builtin_bswap64(code), 3 * K1);
+}
+
+__attribute__((target("bmi2"))) bool pack_row_bmi2(const uint8_t *s, uint32_t len, uint32_t *row)
+{
+    uint64_t bad = 0;
+    uint32_t j = 0;
+    for (; j + 16 <= len; j += 16) {
+        uint64_t a, b;
+        memcpy(&a, s + j, 8);
+        memcpy(&b, s + j + 8, 8);
+        row[j >> 4] = (pack8(a, bad) << 16) | pack8(b, bad);
+    }
+    if (bad) return false;
+    uint32_t sb = 0;
+    for (; j < len; j++) {
+        const uint32_t c = kSym.t[s[j]];
+        sb |= c;
+        row[j >> 4] |= (c & 3u) << (30u - 2u * (j & 15u));
+    }
+    return !(sb & 0x80u);
+}
+#endif
+
 void pack_range(const uint8_t *bases, const uint64_t *offsets, uint64_t lo, uint64_t hi, uint32_t h,
                 uint32_t sw, uint32_t *packed, uint8_t *lens, uint64_t *skipped)
 {
+#if defined(__x86_64__)
+    const bool fast = __builtin_cpu_supports("bmi2");
+#else
+    const bool fast = false;
+#endif
     uint64_t sk = 0;
     for (uint64_t r = lo; r < hi; r++) {
         uint32_t *row = packed + r * sw;
@@ -40,13 +97,13 @@ void pack_range(const uint8_t *bases, const uint64_t *offsets, uint64_t lo, uint
         const uint64_t len = offsets[r + 1] - offsets[r];
         if (len < h || len > 255 || len > (uint64_t)sw * 16) { lens[r] = 0; sk++; continue; }
         const uint8_t *s = bases + offsets[r];
-        uint32_t bad = 0;
-        for (uint32_t j = 0; j < (uint32_t)len; j++) {
-            uint32_t c = kSym.t[s[j]];
-            bad |= c;
-            row[j >> 4] |= (c & 3u) << (30u - 2u * (j & 15u));
-        }
-        if (bad & 0x80u) { memset(row, 0, (size_t)sw * 4); lens[r] = 0; sk++; }
+        bool ok;
+#if defined(__x86_64__)
+        ok = fast ? pack_row_bmi2(s, (uint32_t)len, row) : pack_row_scalar(s, (uint32_t)len, row);
+#else
+        ok = pack_row_scalar(s, (uint32_t)len, row);
+#endif
+        if (!ok) { memset(row, 0, (size_t)sw * 4); lens[r] = 0; sk++; }
         else lens[r] = (uint8_t)len;
     }
     *skipped = sk;

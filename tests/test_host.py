@@ -172,3 +172,34 @@ def test_packer_large_multithreaded():
     for j in range(L):
         want[:, j >> 4] |= sym[:, j] << np.uint32(30 - 2 * (j & 15))
     assert np.array_equal(packed, want)
+
+
+def test_packer_fuzz_all_byte_values():
+    """Every byte value at every alignment: the SWAR/PEXT fast path must agree with the
+    byte-by-byte definition (valid iff all bytes in ACGTacgt; 2-bit codes A0 C1 G2 T3)."""
+    rng = np.random.default_rng(5)
+    reads = []
+    for i in range(4000):
+        L = int(rng.integers(5, 256))
+        r = np.frombuffer(b"ACGTacgt", np.uint8)[rng.integers(0, 8, size=L)].copy()
+        if i % 3 == 0:
+            r[int(rng.integers(0, L))] = int(rng.integers(0, 256))
+        reads.append(r.tobytes())
+    for v in range(256):            # each byte value once, mid-word
+        reads.append(b"ACGTACGTACG" + bytes([v]) + b"TTGCA" * 4)
+    b, o = synth.concat_reads(reads)
+    packed, lens, sk = cq.pack_reads(b, o, 5)
+    ok = set(b"ACGTacgt")
+    nbad = 0
+    for r, read in enumerate(reads):
+        valid = all(c in ok for c in read)
+        if not valid:
+            nbad += 1
+            assert lens[r] == 0 and not packed[r].any(), (r, read)
+            continue
+        assert lens[r] == len(read)
+        want = np.zeros(packed.shape[1], np.uint32)
+        for j, c in enumerate(read):
+            want[j >> 4] |= np.uint32(synth.SYM[c] << (30 - 2 * (j & 15)))
+        assert np.array_equal(packed[r], want), r
+    assert sk == nbad
