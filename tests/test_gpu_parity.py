@@ -208,3 +208,40 @@ def test_size_independent_properties_at_scale(tmp_path):
                rcount_d=rc.cpu().numpy().view(np.uint32)[ix.n_leaves[0]:])
     assert_same(got, whole, "device api")
     assert ix.last_kernel_ms() > 0
+
+
+@pytest.mark.parametrize("share", [0.0, 0.3])
+def test_benchmark_generator_world_matches_oracle(tmp_path, share):
+    """The generator bench.py uses (csrc/cq_synth.cpp), at a size the oracle handles in seconds:
+    unique-only and unique + doubly-unique, 150 bp reads (configs[4] read length)."""
+    from cammiq_amd import bigsynth
+    w = bigsynth.World(seed=9, n_genomes=24, genome_len=60000, pair_share=share)
+    pu = str(tmp_path / "index_u.bin1")
+    pd = str(tmp_path / "index_d.bin2") if share else None
+    nu, nd = w.write_index(pu, pd)
+    assert nu > 0 and (nd > 0) == bool(share)
+    for rl in (100, 150):
+        b, o = w.reads(seed=3, n=40000, length=rl)
+        got = cq.Index(pu, pd, device=0).query(b, o, 24)
+        ref = oracle_lib.OracleIndex(pu, pd).query(b, o, 24, nthreads=8)
+        assert_same(got, ref, f"bigsynth share={share} rl={rl}")
+        assert got["nskipped"] == 0
+
+
+def test_many_genomes_use_global_counters(tmp_path):
+    """n_genomes above the LDS-histogram limit (4095) switches the per-genome counters to
+    global atomics; results must not change."""
+    gen = synth.clade_genomes(41, 3, 3, 2500, 0.03)
+    u, d = synth.select_markers(gen, 22, 34, keep_every=2, seed=2)
+    # spread the nine genomes' refIDs over a large id space
+    remap = {i + 1: 1 + i * 1700 for i in range(len(gen))}
+    u2 = {k: (remap[r], c) for k, (r, c) in u.items()}
+    d2 = {k: (remap[a], remap[b], c1, c2) for k, (a, b, c1, c2) in d.items()}
+    pu, pd = build_index(tmp_path, u2, d2, 22)
+    reads = synth.simulate_reads(gen, 6000, (30, 200), 0.01, 3, frac_random=0.1)
+    G = 15000
+    for mode in (0, 1):
+        got, ref = _both(pu, pd, reads, G, mode)
+        assert_same(got, ref, f"G={G} mode={mode}", rcount=(mode == 0))
+        assert got["pairs"] == ref["pairs"]
+    assert int(ref["cnt_u"][remap[9]]) > 0
