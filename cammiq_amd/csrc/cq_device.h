@@ -32,14 +32,14 @@ typedef struct cq_slot {
  * A window's forward h-mer F and its reverse complement R are BOTH looked up (the reference
  * scans both strands, query.cpp:480-527), and neighbouring windows overlap in h-1 bases.
  * Keys are therefore not placed by hash(key) but by hash(minimizer(key)): the canonical
- * m-mer (m = min(h, 15)) that minimises a bijective 32-bit hash phi over all m-mers of the
+ * m-mer (m = min(h, 16)) that minimises a bijective 32-bit hash phi over all m-mers of the
  * key and of its reverse complement (only the minimum phi itself is used).  Consequences:
  *   * F and R have the same minimizer -> ONE bucket chain serves both strand lookups;
  *   * consecutive windows share their minimizer for ~(h-m+2)/2 positions -> adjacent lanes
  *     read the SAME 64-byte bucket and the memory system serves them with one HBM access.
  * Random HBM accesses per read drop from 2(rl-h+1) to about 2(rl-h+1)/(h-m+2)  (150 -> ~12
  * for rl=100, h=26); lookups stay exact because every slot still holds the full key. */
-#define CQ_MAX_MINIMIZER 15
+#define CQ_MAX_MINIMIZER 16
 
 CQ_HD uint32_t cq_minimizer_len(uint32_t h) { return h < CQ_MAX_MINIMIZER ? h : CQ_MAX_MINIMIZER; }
 
@@ -72,7 +72,7 @@ CQ_HD uint32_t cq_rev2_32(uint32_t x)
     return __builtin_bswap32(x);
 }
 
-/* phi of the canonical form of the m-mer f (m <= 15, f in the low 2m bits). */
+/* phi of the canonical form of the m-mer f (m <= 16, f in the low 2m bits). */
 CQ_HD uint32_t cq_mmer_phi(uint32_t f, uint32_t m)
 {
     const uint32_t r = (~cq_rev2_32(f)) >> (32u - 2u * m);
@@ -83,7 +83,7 @@ CQ_HD uint32_t cq_mmer_phi(uint32_t f, uint32_t m)
  * the m-mers of the reverse complement are the reverse complements of these m-mers. */
 CQ_HD uint32_t cq_min_phi(uint64_t hmer, uint32_t h, uint32_t m)
 {
-    const uint32_t mask = (1u << (2u * m)) - 1u;
+    const uint32_t mask = m >= 16 ? 0xFFFFFFFFu : (1u << (2u * m)) - 1u;
     uint32_t best = 0xFFFFFFFFu;
     for (uint32_t j = 0; j + m <= h; j++) {
         const uint32_t p = cq_mmer_phi((uint32_t)(hmer >> (2u * (h - m - j))) & mask, m);

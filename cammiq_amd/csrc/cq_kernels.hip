@@ -350,7 +350,7 @@ __global__ void __launch_bounds__(kBlock) classify_kernel(DevIndex ix, QueryArgs
     if (SLOW) n_reads = *a.ovf_count < a.ovf_cap ? *a.ovf_count : a.ovf_cap;
     const uint64_t n_sub = (n_reads + R - 1) / R;
     const uint64_t wave_gid = (uint64_t)blockIdx.x * kWaves + wave, n_waves = (uint64_t)gridDim.x * kWaves;
-    const uint32_t mmask = (1u << (2u * m)) - 1u;
+    const uint32_t mmask = m >= 16 ? 0xFFFFFFFFu : (1u << (2u * m)) - 1u;
 
     for (uint64_t sub = wave_gid; sub < n_sub; sub += n_waves) {
         const uint64_t r0 = sub * R;
