@@ -50,7 +50,11 @@ def main():
     ap.add_argument("--read-len", type=int, default=100)
     ap.add_argument("--both", action="store_true", help="unique + doubly-unique index (configs[2] shape)")
     ap.add_argument("--cpu-sample", type=int, default=2_000_000, help="reads timed through the CPU oracle (0 = skip)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true",
+                    help="skip the CPU oracle leg and its parity gate (used under rocprofv3 so that every "
+                         "classify launch in the trace is a full-size timed step)")
+    ap.add_argument("--host-api", action="store_true",
+                    help="also time cq_query on host ASCII reads (PCIe-inclusive rate; never `value`)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -187,7 +191,7 @@ def main():
 
         # ---- PCIe-inclusive rate of the host-buffer API (never `value`): ASCII reads in host
         #      memory -> pack -> H2D -> kernel -> D2H, chunks pipelined inside cq_query
-        if rank == 0 and world == 1:
+        if rank == 0 and world == 1 and args.host_api:
             ix.query(bases[:args.read_len * 1000], offs[:1001], G)          # warm the staging buffers
             t0 = time.perf_counter()
             hq = ix.query(bases, offs, G)
