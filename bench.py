@@ -48,6 +48,8 @@ def main():
     ap.add_argument("--genome-len", type=int, default=3_450_000)
     ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU per step")
     ap.add_argument("--read-len", type=int, default=100)
+    ap.add_argument("--frac-deep", type=float, default=0.07,
+                    help="fraction of markers longer than k (trie depth > 0); 0.07 is what the survey measured")
     ap.add_argument("--both", action="store_true", help="unique + doubly-unique index (configs[2] shape)")
     ap.add_argument("--cpu-sample", type=int, default=2_000_000, help="reads timed through the CPU oracle (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true",
@@ -85,7 +87,7 @@ def main():
     wdir = os.path.join(shm, f"cammiq_bench_{os.environ.get('MASTER_PORT', os.getpid())}")
     try:
         w = bigsynth.World(seed=2, n_genomes=G, genome_len=args.genome_len, k=k, h=h, lmax=50,
-                           pair_share=0.3 if args.both else 0.0)
+                           frac_deep=args.frac_deep, pair_share=0.3 if args.both else 0.0)
         pu = os.path.join(wdir, "index_u.bin1")
         pd = os.path.join(wdir, "index_d.bin2") if args.both else None
         if local_rank == 0:

@@ -203,3 +203,37 @@ def test_packer_fuzz_all_byte_values():
             want[j >> 4] |= np.uint32(synth.SYM[c] << (30 - 2 * (j & 15)))
         assert np.array_equal(packed[r], want), r
     assert sk == nbad
+
+
+def test_loader_survives_corrupted_files(tmp_path):
+    """Bit flips, truncations and garbage must come back as status codes (the reference asserts
+    or walks off its buffers); a file that still loads must decode like the oracle does."""
+    import random
+    gen = synth.clade_genomes(3, 1, 3, 800, 0.05)
+    u, d = synth.select_markers(gen, 12, 20, keep_every=2, seed=1)
+    pu, pd = build_index(tmp_path, u, d, 10, "fz")
+    good = {p: open(p, "rb").read() for p in (pu, pu + ".aux", pd, pd + ".aux")}
+    rng = random.Random(7)
+    loaded = failed = 0
+    for trial in range(120):
+        victim = rng.choice(list(good))
+        data = bytearray(good[victim])
+        kind = trial % 3
+        if kind == 0:
+            for _ in range(rng.randrange(1, 4)):
+                i = rng.randrange(len(data)); data[i] ^= 1 << rng.randrange(8)
+        elif kind == 1:
+            data = data[:rng.randrange(0, len(data))]
+        else:
+            i = rng.randrange(len(data)); data[i:i + 8] = bytes(rng.randrange(256) for _ in range(8))
+        open(victim, "wb").write(bytes(data))
+        try:
+            ix = cq.Index(pu, pd, device=-1)
+            loaded += 1
+            assert ix.n_leaves[0] >= 0 and ix.info.max_chain < 1000
+            ix.close()
+        except cq.CammiqError as e:
+            failed += 1
+            assert e.code in (-2, -3, -4, -9), e
+        open(victim, "wb").write(good[victim])
+    assert failed > 20 and loaded + failed == 120
