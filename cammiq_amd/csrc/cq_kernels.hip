@@ -140,9 +140,20 @@ __device__ __forceinline__ uint32_t div_small(uint32_t idx, uint32_t d, uint32_t
     return __umul24(idx, magic) >> 19;
 }
 
-// hashtrie.cpp:350-369 on the array trie.  `code` is the bucket root; returns the global
-// leaf id or 0xFFFFFFFF.  Forward strand consumes bases p+h, p+h+1, ...; the reverse strand
-// consumes the complements of p-1, p-2, ... (that IS rc_read[i+h+j], query.cpp:447-450).
+// The 64 bits of a staged row that start at base `off` (rows carry two zero pad words).
+__device__ __forceinline__ uint64_t row_bits64(const uint32_t *row, uint32_t off)
+{
+    const uint32_t q = off >> 4, s = (off & 15u) * 2u;
+    const uint64_t x = ((uint64_t)row[q] << 32) | row[q + 1];
+    return (x << s) | (((uint64_t)row[q + 2] << s) >> 32);
+}
+
+// hashtrie.cpp:350-369 on the path-compressed array trie.  `code` is the bucket root; returns
+// the global leaf id or 0xFFFFFFFF.  The forward strand consumes bases p+h, p+h+1, ...; the
+// reverse strand consumes the complements of p-1, p-2, ... (that IS rc_read[i+h+j],
+// query.cpp:447-450).  A chain node stands for `len` single-child inner nodes: the walk
+// either matches all of its symbols or ends without a leaf, exactly like the symbol-by-symbol
+// loop (inner nodes are never leaves; running out of read inside the chain returns NULL).
 __device__ __forceinline__ uint32_t walk_trie(const DevIndex &ix, const uint32_t *row, uint32_t len,
                                               uint32_t code, uint32_t strand, uint32_t p)
 {
@@ -152,12 +163,24 @@ __device__ __forceinline__ uint32_t walk_trie(const DevIndex &ix, const uint32_t
     for (;;) {
         if (code & CQ_LEAF_BIT) return code & ~CQ_LEAF_BIT;   // cur->isEnd
         if (j == rem) return 0xFFFFFFFFu;                       // read exhausted on an inner node
-        uint32_t sym = strand ? (3u - row_base(row, p - 1u - j)) : row_base(row, p + h + j);
-        uint4 n = ix.nodes[code];
-        uint32_t c = sym == 0 ? n.x : sym == 1 ? n.y : sym == 2 ? n.z : n.w;
-        if (c == 0) return 0xFFFFFFFFu;                          // children[index] == NULL
-        code = c;
-        j++;
+        const uint4 n = ix.nodes[code];
+        if ((n.x >> 30) == 1u) {                                // chain: n.x = CQ_CHAIN_BIT | L
+            const uint32_t L = n.x & 63u;
+            if (rem - j < L) return 0xFFFFFFFFu;                // the read ends inside the chain
+            uint64_t syms;
+            if (!strand) syms = row_bits64(row, p + h + j) >> (64u - 2u * L);
+            else syms = (~rev2(row_bits64(row, p - j - L) >> (64u - 2u * L))) >> (64u - 2u * L);
+            const uint64_t label = (((uint64_t)n.y << 32) | n.z) >> (64u - 2u * L);
+            if (syms != label) return 0xFFFFFFFFu;              // some children[index] == NULL
+            j += L;
+            code = n.w;
+        } else {
+            const uint32_t sym = strand ? (3u - row_base(row, p - 1u - j)) : row_base(row, p + h + j);
+            const uint32_t c = sym == 0 ? n.x : sym == 1 ? n.y : sym == 2 ? n.z : n.w;
+            if (c == 0) return 0xFFFFFFFFu;                      // children[index] == NULL
+            code = c;
+            j++;
+        }
     }
 }
 

@@ -12,7 +12,8 @@
 //     Collisions stay inside the home bucket; a full bucket sets an overflow bit and spills
 //     to the next bucket(s).  A lookup that does not see the overflow bit stops after one
 //     bucket -- which is what most of the (miss-dominated) probes do.
-//   * a linked array trie (16-byte nodes, 4 child codes) for keys longer than h.
+//   * a linked, path-compressed array trie (16-byte nodes: 4 child codes, or a chain of up to
+//     32 symbols + next) for keys longer than h.
 //   * leaf refIDs as two flat uint32 arrays indexed by global leaf id (u leaves first).
 //
 // Placement is a deterministic sort + linear sweep (no hashing races, sequential writes):
@@ -75,6 +76,59 @@ void sort_entries(std::vector<Entry> &e, uint32_t n_buckets)
     for (auto &x : th) x.join();
 }
 
+// Path compression of the array trie.  The reference walks one heap node per base
+// (hashtrie.cpp:350-369); on the GPU every level is a dependent ~1 us memory round trip, and a
+// key longer than h is almost always the only key below its bucket, i.e. a single-child chain.
+// A chain of up to 32 single-child inner nodes becomes ONE 16-byte node
+//     { CQ_CHAIN_BIT | len, label_hi, label_lo, next }      label = len symbols, top aligned
+// so a 50-base key below a 26-base bucket costs one node read instead of 24.  Branch nodes keep
+// the 4-children form.  find64_p's semantics carry over: inner chain nodes are never leaves
+// (keys are prefix-free and leaves have no children), so "consume len matching symbols or fail"
+// is exactly what the symbol-by-symbol walk does.
+struct Compressor {
+    const std::vector<Node> &in;
+    std::vector<Node> &out;
+    uint32_t run(uint32_t code)
+    {
+        if (code == 0 || (code & CQ_LEAF_BIT)) return code;
+        uint32_t head = 0;
+        int64_t link = -1;   // chain node whose `next` still has to be filled in (-1: head)
+        auto set_link = [&](uint32_t v) { if (link < 0) head = v; else out[(size_t)link].child[3] = v; };
+        auto push_chain = [&](uint32_t len, uint64_t label) {
+            const uint64_t top = label << (64u - 2u * len);
+            out.push_back(Node{{CQ_CHAIN_BIT | len, (uint32_t)(top >> 32), (uint32_t)top, 0}});
+            const uint32_t idx = (uint32_t)(out.size() - 1);
+            set_link(idx);
+            link = idx;
+        };
+        uint32_t cur = code, len = 0;
+        uint64_t label = 0;
+        for (;;) {
+            const Node n = in[cur];
+            int cnt = 0, only = -1;
+            for (int c = 0; c < 4; c++) if (n.child[c]) { cnt++; only = c; }
+            if (cnt == 0) { set_link(0); return head; }   // cannot happen: childless nodes are leaves
+            if (cnt == 1) {
+                label = (label << 2) | (uint64_t)only;
+                len++;
+                const uint32_t nxt = n.child[only];
+                const bool leaf = (nxt & CQ_LEAF_BIT) != 0;
+                if (len == 32 || leaf) { push_chain(len, label); len = 0; label = 0; }
+                if (leaf) { set_link(nxt); return head; }
+                cur = nxt;
+                continue;
+            }
+            if (len) push_chain(len, label);
+            out.push_back(Node{{0, 0, 0, 0}});
+            const uint32_t b = (uint32_t)(out.size() - 1);
+            set_link(b);
+            for (int c = 0; c < 4; c++)
+                if (n.child[c]) { const uint32_t v = run(n.child[c]); out[b].child[c] = v; }
+            return head;
+        }
+    }
+};
+
 }  // namespace
 
 int build_image(const DecodedTable &u, const DecodedTable &d, double keys_per_bucket,
@@ -91,9 +145,9 @@ int build_image(const DecodedTable &u, const DecodedTable &d, double keys_per_bu
     // ---- link the two tries into one node array; give leaves global ids (u first)
     const uint64_t nnu = u.nodes.size() - 1, nnd = d.nodes.size() - 1;  // real nodes (index 0 = dummy)
     if (nnu + nnd + 1 >= 0x7FFFFFFFull) { err = "more than 2^31-1 trie nodes in total"; return CQ_ERR_LIMIT; }
-    img.nodes.resize(1 + nnu + nnd);
-    img.nodes[0] = Node{{0, 0, 0, 0}};
-    for (uint64_t i = 1; i <= nnu; i++) img.nodes[i] = u.nodes[i];  // u codes are already global
+    std::vector<Node> linked(1 + nnu + nnd);
+    linked[0] = Node{{0, 0, 0, 0}};
+    for (uint64_t i = 1; i <= nnu; i++) linked[i] = u.nodes[i];  // u codes are already global
     const uint32_t node_off = (uint32_t)nnu, leaf_off = (uint32_t)nu;
     auto relink_d = [&](uint32_t code) -> uint32_t {
         if (code == 0) return 0;
@@ -103,8 +157,12 @@ int build_image(const DecodedTable &u, const DecodedTable &d, double keys_per_bu
     for (uint64_t i = 1; i <= nnd; i++) {
         Node n = d.nodes[i];
         for (int c = 0; c < 4; c++) n.child[c] = relink_d(n.child[c]);
-        img.nodes[nnu + i] = n;
+        linked[nnu + i] = n;
     }
+    // the device gets the path-compressed form (bucket roots are compressed where they are used)
+    img.nodes.clear();
+    img.nodes.push_back(Node{{0, 0, 0, 0}});
+    Compressor comp{linked, img.nodes};
 
     img.leaf_r1.resize(nu + nd);
     img.leaf_r2.resize(nu + nd);
@@ -131,9 +189,11 @@ int build_image(const DecodedTable &u, const DecodedTable &d, double keys_per_bu
     std::vector<Entry> ent;
     ent.reserve(nb_u + nb_d);
     for (uint64_t i = 0; i < nb_u; i++)
-        ent.push_back(Entry{cq_home_bucket(u.bucket_key[i], img.hash_len, n_buckets), (uint32_t)i, u.bucket_key[i], u.bucket_code[i], 0});
+        ent.push_back(Entry{cq_home_bucket(u.bucket_key[i], img.hash_len, n_buckets), (uint32_t)i, u.bucket_key[i], comp.run(u.bucket_code[i]), 0});
     for (uint64_t i = 0; i < nb_d; i++)
-        ent.push_back(Entry{cq_home_bucket(d.bucket_key[i], img.hash_len, n_buckets), (uint32_t)i, d.bucket_key[i], 0, relink_d(d.bucket_code[i])});
+        ent.push_back(Entry{cq_home_bucket(d.bucket_key[i], img.hash_len, n_buckets), (uint32_t)i, d.bucket_key[i], 0, comp.run(relink_d(d.bucket_code[i]))});
+    if (img.nodes.size() >= (1ull << 30)) { err = "more than 2^30 trie nodes after path compression"; return CQ_ERR_LIMIT; }
+    std::vector<Node>().swap(linked);
     sort_entries(ent, n_buckets);
 
     // ---- merge duplicates (same key in both tables, or repeated within one file: the later
