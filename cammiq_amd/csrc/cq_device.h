@@ -14,6 +14,8 @@
 
 #define CQ_LEAF_BIT 0x80000000u
 #define CQ_CHAIN_BIT 0x40000000u          /* word 0 of a path-compressed trie node: CQ_CHAIN_BIT | length */
+#define CQ_INLINE_RID_BIT 0x40000000u     /* slot val_d when ht_d has no such key and val_u is a unique leaf:
+                                             CQ_INLINE_RID_BIT | refID1 of that leaf (saves the leaf_rids read) */
 #define CQ_EMPTY_KEY 0xFFFFFFFFFFFFFFFFull
 #define CQ_OVERFLOW_BIT (1ull << 62)      /* set on slot 0's key of a bucket that spilled */
 #define CQ_KEY_MASK (~(3ull << 62))       /* h <= 31  =>  hv < 2^62 (query.cpp:482-485) */

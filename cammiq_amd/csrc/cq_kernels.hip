@@ -195,6 +195,20 @@ __device__ __forceinline__ void wave_sync()
 
 // Resolve one candidate: walk the trie below the bucket root (most codes are depth-0 leaves
 // already), fetch the leaf's refIDs, append to the read's hit list.
+// Append one hit (global leaf id + its refIDs) to the read's hit list.
+template <int CAP>
+__device__ __forceinline__ void append_hit(const Tile &t, uint32_t rl, uint32_t gid, uint32_t r1, uint32_t r2)
+{
+    const uint32_t k = atomicAdd(&t.hitcnt[rl], 1u);
+    if (k < (uint32_t)CAP) {
+        t.hit_gid[rl * CAP + k] = gid;
+        t.hit_r1[rl * CAP + k] = r1;
+        t.hit_r2[rl * CAP + k] = r2;
+    }
+}
+
+// Resolve one candidate: walk the trie below the bucket root (most codes are depth-0 leaves
+// already), fetch the leaf's refIDs, append to the read's hit list.
 template <int CAP>
 __device__ __forceinline__ void resolve(const DevIndex &ix, const Tile &t, const uint32_t *row, uint32_t len,
                                         uint32_t rl, uint32_t code, uint32_t strand, uint32_t p)
@@ -202,13 +216,22 @@ __device__ __forceinline__ void resolve(const DevIndex &ix, const Tile &t, const
     const uint32_t gid = walk_trie(ix, row, len, code, strand, p);
     if (gid != 0xFFFFFFFFu) {
         const uint2 rr = ix.leaf_rids[gid];
-        const uint32_t k = atomicAdd(&t.hitcnt[rl], 1u);
-        if (k < (uint32_t)CAP) {
-            t.hit_gid[rl * CAP + k] = gid;
-            t.hit_r1[rl * CAP + k] = rr.x;
-            t.hit_r2[rl * CAP + k] = rr.y;
-        }
+        append_hit<CAP>(t, rl, gid, rr.x, rr.y);
     }
+}
+
+// A slot's (val_u, val_d) pair for one strand.  The common case -- a unique marker of length
+// h, nothing in ht_d -- has the leaf's refID inline in val_d: no trie walk, no leaf_rids read.
+template <int CAP>
+__device__ __forceinline__ void resolve_pair(const DevIndex &ix, const Tile &t, const uint32_t *row, uint32_t len,
+                                             uint32_t rl, uint2 v, uint32_t strand, uint32_t p)
+{
+    if ((v.y >> 30) == 1u) {                                       // CQ_INLINE_RID_BIT
+        append_hit<CAP>(t, rl, v.x & ~CQ_LEAF_BIT, v.y & ~CQ_INLINE_RID_BIT, 0u);
+        return;
+    }
+    if (v.x) resolve<CAP>(ix, t, row, len, rl, v.x, strand, p);   // ht_u
+    if (v.y) resolve<CAP>(ix, t, row, len, rl, v.y, strand, p);   // ht_d
 }
 
 // The exact lookup of one window (both strands): full 64-bit key compare along the bucket
@@ -233,10 +256,8 @@ __device__ __forceinline__ void lookup_window(const DevIndex &ix, const Tile &t,
         const Bucket bk = load_bucket(ix.slots, b++);
         more = match_bucket(bk, fw, rc, vf, vr, ff, fr);
     } while (more);
-    if (vf.x) resolve<CAP>(ix, t, row, len, rl, vf.x, 0, pw);   // ht_u, forward strand
-    if (vf.y) resolve<CAP>(ix, t, row, len, rl, vf.y, 0, pw);   // ht_d, forward strand
-    if (vr.x) resolve<CAP>(ix, t, row, len, rl, vr.x, 1, pw);   // ht_u, reverse strand
-    if (vr.y) resolve<CAP>(ix, t, row, len, rl, vr.y, 1, pw);   // ht_d, reverse strand
+    if (vf.x | vf.y) resolve_pair<CAP>(ix, t, row, len, rl, vf, 0, pw);   // forward strand
+    if (vr.x | vr.y) resolve_pair<CAP>(ix, t, row, len, rl, vr, 1, pw);   // reverse strand
 }
 
 // Drain this wave's work list (n <= kWorkCap items: .x = bucket, .y = read | window << 8).

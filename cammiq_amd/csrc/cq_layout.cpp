@@ -209,6 +209,11 @@ int build_image(const DecodedTable &u, const DecodedTable &d, double keys_per_bu
             if (ent[k].val_u && (!hu || ent[k].seq >= su)) { m.val_u = ent[k].val_u; su = ent[k].seq; hu = true; }
             if (ent[k].val_d && (!hd || ent[k].seq >= sd)) { m.val_d = ent[k].val_d; sd = ent[k].seq; hd = true; }
         }
+        // a unique depth-0 leaf with a free val_d slot carries its refID inline (cq_device.h)
+        if ((m.val_u & CQ_LEAF_BIT) && m.val_d == 0) {
+            const uint32_t g = m.val_u & ~CQ_LEAF_BIT;
+            if (img.leaf_r2[g] == 0 && img.leaf_r1[g] < CQ_INLINE_RID_BIT) m.val_d = CQ_INLINE_RID_BIT | img.leaf_r1[g];
+        }
         ent[w++] = m;
         i = j;
     }
@@ -259,6 +264,7 @@ void image_lookup(const FlatImage &img, uint64_t key, uint32_t &val_u, uint32_t 
             uint64_t sk = (k == 0) ? (s[k].key & ~CQ_OVERFLOW_BIT) : s[k].key;
             if (s[k].key != CQ_EMPTY_KEY && sk == key) {
                 val_u = s[k].val_u; val_d = s[k].val_d;
+                if ((val_d >> 30) == 1u) val_d = 0;   // inline refID of the u leaf, not an ht_d entry
                 if (chain_len) *chain_len = chain;
                 return;
             }
