@@ -17,19 +17,29 @@
 #define CQ_INLINE_RID_BIT 0x40000000u     /* slot val_d when ht_d has no such key and val_u is a unique leaf:
                                              CQ_INLINE_RID_BIT | refID1 of that leaf (saves the leaf_rids read) */
 #define CQ_EMPTY_KEY 0xFFFFFFFFFFFFFFFFull
-#define CQ_OVERFLOW_BIT (1ull << 62)      /* set on slot 0's key of a bucket that spilled */
 #define CQ_KEY_MASK (~(3ull << 62))       /* h <= 31  =>  hv < 2^62 (query.cpp:482-485) */
-#define CQ_SLOTS_PER_BUCKET 4             /* 4 x 16 B = one 64-byte HBM access */
+#define CQ_SLOTS_PER_BUCKET 4             /* 4 slots x 16 B = one 64-byte HBM access */
 #define CQ_SPILL_TAIL 64                  /* extra buckets past the hash range, no wrap-around */
 
-/* One slot of the merged unique + doubly-unique table.  key = the 2h-bit packed h-mer (the
- * reference's map64 key).  val_u / val_d = trie code of the bucket root in ht_u / ht_d:
- * 0 absent, CQ_LEAF_BIT|global leaf id, or trie node index. */
-typedef struct cq_slot {
-    uint64_t key;
-    uint32_t val_u;
-    uint32_t val_d;
-} cq_slot;
+/* One bucket of the merged unique + doubly-unique table: 64 bytes, 4 slots, stored as a
+ * structure of arrays so that the probe loop's DETECT step is ONE 16-byte load per lane:
+ *
+ *   word  0.. 3  key_lo[4]  low 32 bits of the 2h-bit packed h-mer (the reference's map64 key);
+ *                           bit 0 of key_lo[0] is the bucket's OVERFLOW flag instead
+ *   word  4.. 7  key_hi[4]  high 32 bits (< 2^30); bit 30 of key_hi[0] keeps slot 0's true bit 0
+ *   word  8..11  val_u[4]   trie code of the bucket root in ht_u: 0 absent,
+ *   word 12..15  val_d[4]   CQ_LEAF_BIT|global leaf id, or trie node index (same for ht_d;
+ *                           or CQ_INLINE_RID_BIT|refID1, see above)
+ *
+ * An empty slot has key_hi = 0xFFFFFFFF (no valid key) and key_lo = 0xFFFFFFFF, except slot 0
+ * whose key_lo is 0xFFFFFFFE so that the overflow flag reads 0.  A bucket whose overflow flag is
+ * set is full and at least one key homed at or before it lives further on. */
+#define CQ_BUCKET_WORDS 16
+#define CQ_BW_KEY_LO 0
+#define CQ_BW_KEY_HI 4
+#define CQ_BW_VAL_U 8
+#define CQ_BW_VAL_D 12
+#define CQ_SLOT0_BIT0_IN_HI (1u << 30)
 
 /* ---- minimizer addressing -------------------------------------------------------------
  * A window's forward h-mer F and its reverse complement R are BOTH looked up (the reference

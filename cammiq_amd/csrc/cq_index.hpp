@@ -43,7 +43,7 @@ struct FlatImage {
     uint64_t n_overflowed = 0;
     uint32_t max_chain = 1;
     uint32_t max_refid = 0;
-    std::vector<cq_slot> slots;   // 4 per bucket
+    std::vector<uint32_t> table;  // CQ_BUCKET_WORDS words per bucket (layout in cq_device.h)
     std::vector<Node> nodes;      // linked: d-table indices/leaf ids already offset
     std::vector<uint32_t> leaf_r1, leaf_r2;  // global leaf id -> refIDs (u leaves first)
 };

@@ -11,7 +11,7 @@ namespace cq {
 
 // Device view of the index (all pointers into HBM).
 struct DevIndex {
-    const uint4 *slots;      // n_buckets_alloc * 4 slots of 16 B (cq_slot)
+    const uint4 *slots;      // n_buckets_alloc buckets of 4 x uint4: key_lo | key_hi | val_u | val_d (cq_device.h)
     const uint4 *nodes;      // array trie, 16 B per node
     const uint2 *leaf_rids;  // global leaf id -> (refID1, refID2)
     uint32_t n_buckets;      // hash range

@@ -56,34 +56,38 @@ __device__ __forceinline__ uint64_t rev2(uint64_t x)
     return ((y >> 1) & 0x5555555555555555ull) | ((y & 0x5555555555555555ull) << 1);
 }
 
-// One 64-byte bucket.
-struct Bucket { uint4 s[4]; };
+// One 64-byte bucket, structure of arrays (cq_device.h): lo = key_lo[4], hi = key_hi[4],
+// vu = val_u[4], vd = val_d[4].
+struct Bucket { uint4 lo, hi, vu, vd; };
 
 __device__ __forceinline__ Bucket load_bucket(const uint4 *__restrict__ slots, uint32_t b)
 {
     const uint4 *p = slots + (size_t)b * 4;
     Bucket r;
-    r.s[0] = p[0]; r.s[1] = p[1]; r.s[2] = p[2]; r.s[3] = p[3];
+    r.lo = p[0]; r.hi = p[1]; r.vu = p[2]; r.vd = p[3];
     return r;
 }
 
 // Compare the four slots with the forward h-mer and with its reverse complement (both live
 // in the same bucket chain: same minimizer).  vf/vr = (val_u, val_d) of the slot holding
-// fw / rc.  Returns true when the chain continues: overflow bit set and not both found.
+// fw / rc.  Returns true when the chain continues: overflow flag set and not both found.
 __device__ __forceinline__ bool match_bucket(const Bucket &bk, uint64_t fw, uint64_t rc, uint2 &vf, uint2 &vr,
                                              bool &ff, bool &fr)
 {
     const uint32_t flo = (uint32_t)fw, fhi = (uint32_t)(fw >> 32);
     const uint32_t rlo = (uint32_t)rc, rhi = (uint32_t)(rc >> 32);
+    // slot 0 lends bit 0 of its key_lo to the overflow flag; the true bit sits in key_hi[0] bit 30
+    // (an empty slot 0 comes out with hi = 0xBFFFFFFF and never matches)
+    const uint32_t lo[4] = {(bk.lo.x & ~1u) | ((bk.hi.x >> 30) & 1u), bk.lo.y, bk.lo.z, bk.lo.w};
+    const uint32_t hi[4] = {bk.hi.x & ~CQ_SLOT0_BIT0_IN_HI, bk.hi.y, bk.hi.z, bk.hi.w};
+    const uint32_t vu[4] = {bk.vu.x, bk.vu.y, bk.vu.z, bk.vu.w};
+    const uint32_t vd[4] = {bk.vd.x, bk.vd.y, bk.vd.z, bk.vd.w};
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        uint32_t shi = bk.s[k].y;
-        if (k == 0) shi &= ~(1u << 30);  // strip CQ_OVERFLOW_BIT; an empty slot keeps bit 31
-        if (bk.s[k].x == flo && shi == fhi) { vf.x = bk.s[k].z; vf.y = bk.s[k].w; ff = true; }
-        if (bk.s[k].x == rlo && shi == rhi) { vr.x = bk.s[k].z; vr.y = bk.s[k].w; fr = true; }
+        if (lo[k] == flo && hi[k] == fhi) { vf.x = vu[k]; vf.y = vd[k]; ff = true; }
+        if (lo[k] == rlo && hi[k] == rhi) { vr.x = vu[k]; vr.y = vd[k]; fr = true; }
     }
-    // overflow: bit 62 set, bit 63 clear on slot 0 (an EMPTY key has both set)
-    return !(ff && fr) && ((bk.s[0].y >> 30) == 1u);
+    return !(ff && fr) && (bk.lo.x & 1u);
 }
 
 // Base q of a staged row (A=0..T=3).
@@ -468,7 +472,7 @@ __global__ void __launch_bounds__(kBlock) classify_kernel(DevIndex ix, QueryArgs
                 uint32_t mp = ph[0];
                 for (uint32_t i = 1; i < nphi; i++) mp = min(mp, ph[i]);
                 b = cq_bucket_of_minimizer(mp, ix.n_buckets);
-                const Bucket bk = load_bucket(ix.slots, b);
+                const uint4 kl = ix.slots[(size_t)b * 4];      // key_lo[4]: the only bucket read of the hot loop
                 // low word of the forward h-mer: the 32 bits that END at the window's end;
                 // low word of the reverse complement: ~reverse of the 32 bits that START it
                 const uint32_t *row = t.rows + __umul24(rl, swp);
@@ -485,9 +489,9 @@ __global__ void __launch_bounds__(kBlock) classify_kernel(DevIndex ix, QueryArgs
                 // reversal puts the window's first base into the lowest symbol, so the low
                 // 2h bits are exactly the (whole, when h < 16) reverse complement
                 const uint32_t rlo = (~y) & hmask;
-                flag = (bk.s[0].x == flo) | (bk.s[1].x == flo) | (bk.s[2].x == flo) | (bk.s[3].x == flo) |
-                       (bk.s[0].x == rlo) | (bk.s[1].x == rlo) | (bk.s[2].x == rlo) | (bk.s[3].x == rlo) |
-                       ((bk.s[0].y >> 30) == 1u);
+                // slot 0's bit 0 is the overflow flag: compare it without that bit
+                flag = ((kl.x ^ flo) < 2u) | (kl.y == flo) | (kl.z == flo) | (kl.w == flo) |
+                       ((kl.x ^ rlo) < 2u) | (kl.y == rlo) | (kl.z == rlo) | (kl.w == rlo) | ((kl.x & 1u) != 0);
             }
             const uint64_t mask = __ballot(flag);
             if (mask) {

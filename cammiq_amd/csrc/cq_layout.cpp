@@ -3,8 +3,9 @@
 // Replaces the reference's in-memory index (robin_hood::unordered_map<uint64_t, trieNode*>
 // + heap pointer trie, /root/reference/src/hashtrie.hpp:8-13,49; hashtrie.cpp:8-13) by:
 //
-//   * ONE merged open-addressing table for ht_u and ht_d.  A slot is 16 B
-//     {key = hv, val_u, val_d}; 4 slots form a 64-byte bucket = one HBM access, so the two
+//   * ONE merged open-addressing table for ht_u and ht_d: a slot is {key = hv, val_u, val_d},
+//     4 slots form a 64-byte bucket = one HBM access, stored as a structure of arrays
+//     (cq_device.h) so that the probe's detect step reads only the four key_lo words; the two
 //     find64_p calls the reference makes per window (query.cpp:487-492) cost one probe.
 //     A key's home bucket is chosen by its canonical MINIMIZER (cq_device.h), not by the
 //     key itself: both strands of a window, and runs of neighbouring windows, then share one
@@ -222,7 +223,12 @@ int build_image(const DecodedTable &u, const DecodedTable &d, double keys_per_bu
 
     // ---- linear sweep placement
     img.n_buckets_alloc = nbk + CQ_SPILL_TAIL;
-    img.slots.assign(img.n_buckets_alloc * CQ_SLOTS_PER_BUCKET, cq_slot{CQ_EMPTY_KEY, 0, 0});
+    img.table.assign(img.n_buckets_alloc * CQ_BUCKET_WORDS, 0u);
+    for (uint64_t b = 0; b < img.n_buckets_alloc; b++) {
+        uint32_t *bw = &img.table[b * CQ_BUCKET_WORDS];
+        for (int k = 0; k < CQ_SLOTS_PER_BUCKET; k++) bw[CQ_BW_KEY_LO + k] = bw[CQ_BW_KEY_HI + k] = 0xFFFFFFFFu;
+        bw[CQ_BW_KEY_LO] = 0xFFFFFFFEu;   // empty slot 0: overflow flag (bit 0) must read 0
+    }
     size_t next = 0;         // next entry not yet pulled into the carry
     size_t carry_lo = 0;     // entries [carry_lo, next) are waiting for a slot, oldest first
     uint64_t overflowed = 0;
@@ -234,16 +240,24 @@ int build_image(const DecodedTable &u, const DecodedTable &d, double keys_per_bu
             continue;
         }
         size_t take = std::min<size_t>(avail, CQ_SLOTS_PER_BUCKET);
-        cq_slot *s = &img.slots[b * CQ_SLOTS_PER_BUCKET];
+        uint32_t *bw = &img.table[b * CQ_BUCKET_WORDS];
         for (size_t k = 0; k < take; k++) {
             const Entry &e = ent[carry_lo + k];
-            s[k].key = e.key; s[k].val_u = e.val_u; s[k].val_d = e.val_d;
+            uint32_t lo = (uint32_t)e.key, hi = (uint32_t)(e.key >> 32);
+            if (k == 0) {   // slot 0 lends bit 0 of key_lo to the overflow flag
+                if (lo & 1u) hi |= CQ_SLOT0_BIT0_IN_HI;
+                lo &= ~1u;
+            }
+            bw[CQ_BW_KEY_LO + k] = lo;
+            bw[CQ_BW_KEY_HI + k] = hi;
+            bw[CQ_BW_VAL_U + k] = e.val_u;
+            bw[CQ_BW_VAL_D + k] = e.val_d;
             uint32_t chain = (uint32_t)(b - e.home) + 1;
             if (chain > img.max_chain) img.max_chain = chain;
         }
         carry_lo += take;
         if (carry_lo < next) {  // something is still waiting: this bucket is full and spilled
-            s[0].key |= CQ_OVERFLOW_BIT;
+            bw[CQ_BW_KEY_LO] |= 1u;
             overflowed++;
         }
     }
@@ -256,20 +270,25 @@ void image_lookup(const FlatImage &img, uint64_t key, uint32_t &val_u, uint32_t 
 {
     val_u = val_d = 0;
     uint64_t b = cq_home_bucket(key, img.hash_len, (uint32_t)img.n_buckets);
+    const uint32_t klo = (uint32_t)key, khi = (uint32_t)(key >> 32);
     uint32_t chain = 0;
     for (;;) {
-        const cq_slot *s = &img.slots[b * CQ_SLOTS_PER_BUCKET];
+        const uint32_t *bw = &img.table[b * CQ_BUCKET_WORDS];
         chain++;
         for (int k = 0; k < CQ_SLOTS_PER_BUCKET; k++) {
-            uint64_t sk = (k == 0) ? (s[k].key & ~CQ_OVERFLOW_BIT) : s[k].key;
-            if (s[k].key != CQ_EMPTY_KEY && sk == key) {
-                val_u = s[k].val_u; val_d = s[k].val_d;
+            uint32_t lo = bw[CQ_BW_KEY_LO + k], hi = bw[CQ_BW_KEY_HI + k];
+            if (k == 0) {   // undo the bit-0 loan (an empty slot 0 comes out as hi = 0xBFFFFFFF: no match)
+                lo = (lo & ~1u) | ((hi >> 30) & 1u);
+                hi &= ~CQ_SLOT0_BIT0_IN_HI;
+            }
+            if (lo == klo && hi == khi) {
+                val_u = bw[CQ_BW_VAL_U + k]; val_d = bw[CQ_BW_VAL_D + k];
                 if ((val_d >> 30) == 1u) val_d = 0;   // inline refID of the u leaf, not an ht_d entry
                 if (chain_len) *chain_len = chain;
                 return;
             }
         }
-        bool ovf = (s[0].key != CQ_EMPTY_KEY) && (s[0].key & CQ_OVERFLOW_BIT);
+        const bool ovf = (bw[CQ_BW_KEY_LO] & 1u) != 0;
         if (!ovf || b + 1 >= img.n_buckets_alloc) break;
         b++;
     }
