@@ -173,10 +173,10 @@ int cq_index_load(const char *path_u, const char *path_d, int device, cq_index *
         }
         std::string err;
         // Average keys per 4-slot bucket of the device table.  Emptier tables overflow less
-        // (fewer windows take the exact path): 0.75 costs 85 B of HBM per key and is 20 % faster
-        // than 1.5; when the table would not fit comfortably it is packed tighter.
+        // (fewer windows take the exact path): 1.0 costs 64 B of HBM per key (measured: 0.5 -> +2 %,
+        // 1.5 -> -3 %); when the table would not fit comfortably it is packed tighter.
         // CAMMIQ_KEYS_PER_BUCKET overrides (tuning knob, not part of the ABI).
-        double kpb = 0.75;
+        double kpb = 1.0;
         if (device >= 0) {
             size_t free_b = 0, total_b = 0;
             if (hipSetDevice(device) == hipSuccess && hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b) {

@@ -469,8 +469,15 @@ __global__ void __launch_bounds__(kBlock) classify_kernel(DevIndex ix, QueryArgs
             if (act) {
                 // minimizer hash = min over the h-m+1 m-mers of the window
                 const uint32_t *ph = t.phi + __umul24(rl, pmax) + pw;
-                uint32_t mp = ph[0];
-                for (uint32_t i = 1; i < nphi; i++) mp = min(mp, ph[i]);
+                uint32_t mp;
+                if (nphi == 11) {        // h = 26 (CAMMiQ's default): all eleven LDS reads in flight at once
+                    const uint32_t v0 = ph[0], v1 = ph[1], v2 = ph[2], v3 = ph[3], v4 = ph[4], v5 = ph[5],
+                                   v6 = ph[6], v7 = ph[7], v8 = ph[8], v9 = ph[9], v10 = ph[10];
+                    mp = min(min(min(v0, v1), min(v2, v3)), min(min(min(v4, v5), min(v6, v7)), min(min(v8, v9), v10)));
+                } else {
+                    mp = ph[0];
+                    for (uint32_t i = 1; i < nphi; i++) mp = min(mp, ph[i]);
+                }
                 b = cq_bucket_of_minimizer(mp, ix.n_buckets);
                 const uint4 kl = ix.slots[(size_t)b * 4];      // key_lo[4]: the only bucket read of the hot loop
                 // low word of the forward h-mer: the 32 bits that END at the window's end;
