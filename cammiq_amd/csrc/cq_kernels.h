@@ -29,6 +29,7 @@ struct QueryArgs {
     uint32_t magic_w;        // ceil(2^19 / wmax), ceil(2^19 / pmax): exact small divisions
     uint32_t magic_p;
     uint32_t magic_s;        // ceil(2^19 / stride_words)
+    uint32_t magic_pp;       // ceil(2^19 / position pairs per read)
     uint32_t n_genomes;
     int mode;
     uint64_t *counters;      // cq_counter_words(n_genomes)

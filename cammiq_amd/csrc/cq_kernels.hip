@@ -398,7 +398,6 @@ __global__ void __launch_bounds__(kBlock) classify_kernel(DevIndex ix, QueryArgs
     if (SLOW) n_reads = *a.ovf_count < a.ovf_cap ? *a.ovf_count : a.ovf_cap;
     const uint64_t n_sub = (n_reads + R - 1) / R;
     const uint64_t wave_gid = (uint64_t)blockIdx.x * kWaves + wave, n_waves = (uint64_t)gridDim.x * kWaves;
-    const uint32_t mmask = m >= 16 ? 0xFFFFFFFFu : (1u << (2u * m)) - 1u;
 
     for (uint64_t sub = wave_gid; sub < n_sub; sub += n_waves) {
         const uint64_t r0 = sub * R;
@@ -429,17 +428,20 @@ __global__ void __launch_bounds__(kBlock) classify_kernel(DevIndex ix, QueryArgs
         }
         wave_sync();
 
-        // ---- pre-pass: hash the canonical m-mer at every base position, once
+        // ---- pre-pass: hash the canonical m-mer at every base position, once.  A lane takes
+        // two adjacent positions: they share the index arithmetic and the row words.
         {
-            const uint32_t total = nr * pmax;
-            for (uint32_t idx = lane; idx < total; idx += 64) {
-                const uint32_t rl = div_small(idx, pmax, a.magic_p), j = idx - __umul24(rl, pmax);
-                if (j + m <= t.len[rl]) {
+            const uint32_t ppr = (pmax + 1u) >> 1;                 // position pairs per read
+            const uint32_t total = nr * ppr;
+            for (uint32_t it = lane; it < total; it += 64) {
+                const uint32_t rl = div_small(it, ppr, a.magic_pp), j = (it - __umul24(rl, ppr)) * 2u;
+                const uint32_t len = t.len[rl];
+                if (j + m <= len) {
                     const uint32_t *row = t.rows + __umul24(rl, swp);
-                    const uint32_t q = j >> 4, s = (j & 15u) * 2u;
-                    // the 32 bits that start at base j, then keep the first m bases of them
-                    const uint32_t w32 = __funnelshift_l(row[q + 1], row[q], s);
-                    t.phi[idx] = cq_mmer_phi((w32 >> (32u - 2u * m)) & mmask, m);
+                    const uint64_t w64 = row_bits64(row, j);       // 32 bases starting at base j
+                    uint32_t *dst = t.phi + __umul24(rl, pmax) + j;
+                    dst[0] = cq_mmer_phi((uint32_t)(w64 >> (64u - 2u * m)), m);
+                    if (j + 1u + m <= len) dst[1] = cq_mmer_phi((uint32_t)((w64 << 2) >> (64u - 2u * m)), m);
                 }
             }
         }
@@ -570,6 +572,7 @@ hipError_t launch_classify(const DevIndex &ix, QueryArgs a, int n_cus, hipStream
     a.magic_w = magic_of(a.wmax);
     a.magic_p = magic_of(a.pmax);
     a.magic_s = magic_of(a.stride_words);
+    a.magic_pp = magic_of((a.pmax + 1u) >> 1);
     hipError_t e;
     // LDS above the 64 KiB default needs an explicit opt-in (large G)
     e = hipFuncSetAttribute((const void *)classify_kernel<kFastR, kFastCAP, false>,
