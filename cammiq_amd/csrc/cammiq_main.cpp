@@ -12,7 +12,10 @@
 //                  in map_sp order) so a host with a solver can pick it up.
 // Extensions (not in the reference): --device N, --dump_counts FILE, missing .bin2 allowed.
 #include <dirent.h>
+#include <fcntl.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <chrono>
@@ -24,6 +27,7 @@
 #include <set>
 #include <sstream>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/cammiq_hip.h"
@@ -78,28 +82,90 @@ std::vector<Genome> load_map(const std::string &fn)
 // FqReader::readFastq (query.cpp:371-425): second line of every four; reads shorter than
 // min_l are dropped; every 'N' of a read is replaced by ONE random base per read.  The
 // reference seeds rand() from the clock, so its output on reads with N is not reproducible;
-// this shell uses a fixed-seed generator instead (documented deviation).
+// this shell derives the base from the read's index instead (documented deviation).
+// Unlike the reference (one getline + one new[] per read, single thread) the file is
+// memory-mapped and split at line boundaries across threads: count lines, prefix-sum, then
+// copy the sequence lines into one contiguous buffer + offsets, which is what cq_query takes.
 void read_fastq(const std::string &fn, size_t min_l, std::vector<uint8_t> &bases, std::vector<uint64_t> &offs)
 {
-    std::ifstream in(fn);
-    if (!in.is_open()) die("Failed to find input file %s.\n", fn.c_str());
     bases.clear(); offs.assign(1, 0);
-    std::string l;
-    uint64_t lcg = 0x9E3779B97F4A7C15ull;
-    const char alphabet[4] = {'A', 'C', 'G', 'T'};
-    while (std::getline(in, l)) {
-        if (!std::getline(in, l)) break;
-        if (!l.empty() && l.back() == '\r') l.pop_back();
-        if (l.size() >= min_l) {
-            lcg = lcg * 6364136223846793005ull + 1442695040888963407ull;
-            const char sub = alphabet[(lcg >> 60) & 3];
-            for (char &c : l) if (c == 'N') c = sub;
-            bases.insert(bases.end(), l.begin(), l.end());
-            offs.push_back(bases.size());
-        }
-        std::string skip;
-        std::getline(in, skip); std::getline(in, skip);
+    int fd = open(fn.c_str(), O_RDONLY);
+    if (fd < 0) die("Failed to find input file %s.\n", fn.c_str());
+    struct stat st;
+    fstat(fd, &st);
+    const size_t n = (size_t)st.st_size;
+    if (n == 0) { close(fd); fprintf(stderr, "Loaded query file %s.\n", fn.c_str()); return; }
+    const char *p = (const char *)mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
+    if (p == MAP_FAILED) die("Failed to map input file %s.\n", fn.c_str());
+    madvise((void *)p, n, MADV_SEQUENTIAL);
+    unsigned hw = std::thread::hardware_concurrency();
+    const unsigned T = (n < (1u << 22)) ? 1u : std::max(1u, std::min(hw ? hw : 1u, 32u));
+    // chunk c covers [cut[c], cut[c+1]); every cut sits right after a newline
+    std::vector<size_t> cut(T + 1, n);
+    cut[0] = 0;
+    for (unsigned c = 1; c < T; c++) {
+        size_t q = n / T * c;
+        const char *nl = (const char *)memchr(p + q, '\n', n - q);
+        cut[c] = nl ? (size_t)(nl - p) + 1 : n;
     }
+    std::vector<uint64_t> nlines(T, 0);
+    auto for_chunks = [&](auto &&fn_) {
+        std::vector<std::thread> th;
+        for (unsigned c = 0; c < T; c++) th.emplace_back(fn_, c);
+        for (auto &x : th) x.join();
+    };
+    for_chunks([&](unsigned c) {
+        uint64_t k = 0;
+        for (const char *s = p + cut[c], *e = p + cut[c + 1]; s < e;) {
+            const char *nl = (const char *)memchr(s, '\n', (size_t)(e - s));
+            k++;
+            if (!nl) break;
+            s = nl + 1;
+        }
+        nlines[c] = k;
+    });
+    std::vector<uint64_t> line0(T + 1, 0);
+    for (unsigned c = 0; c < T; c++) line0[c + 1] = line0[c] + nlines[c];
+    // pass 2a: per chunk, kept reads and their total length
+    std::vector<uint64_t> nreads(T, 0), nbytes(T, 0);
+    auto walk = [&](unsigned c, auto &&emit) {
+        uint64_t li = line0[c];
+        for (const char *s = p + cut[c], *e = p + cut[c + 1]; s < e; li++) {
+            const char *nl = (const char *)memchr(s, '\n', (size_t)(e - s));
+            size_t len = nl ? (size_t)(nl - s) : (size_t)(e - s);
+            if ((li & 3u) == 1u) {
+                if (len && s[len - 1] == '\r') len--;
+                if (len >= min_l) emit(s, len, li >> 2);
+            }
+            if (!nl) break;
+            s = nl + 1;
+        }
+    };
+    for_chunks([&](unsigned c) { walk(c, [&](const char *, size_t len, uint64_t) { nreads[c]++; nbytes[c] += len; }); });
+    std::vector<uint64_t> r0(T + 1, 0), b0(T + 1, 0);
+    for (unsigned c = 0; c < T; c++) { r0[c + 1] = r0[c] + nreads[c]; b0[c + 1] = b0[c] + nbytes[c]; }
+    bases.resize(b0[T]);
+    offs.resize(r0[T] + 1);
+    offs[r0[T]] = b0[T];
+    // pass 2b: copy
+    const char alphabet[4] = {'A', 'C', 'G', 'T'};
+    for_chunks([&](unsigned c) {
+        uint64_t r = r0[c], b = b0[c];
+        walk(c, [&](const char *s, size_t len, uint64_t rec) {
+            offs[r++] = b;
+            uint8_t *dst = bases.data() + b;
+            memcpy(dst, s, len);
+            if (memchr(dst, 'N', len)) {
+                uint64_t z = (rec + 1) * 0x9E3779B97F4A7C15ull;
+                z ^= z >> 29;
+                const uint8_t sub = (uint8_t)alphabet[(z >> 7) & 3];
+                for (size_t i = 0; i < len; i++) if (dst[i] == 'N') dst[i] = sub;
+            }
+            b += len;
+        });
+    });
+    munmap((void *)p, n);
+    close(fd);
     fprintf(stderr, "Loaded query file %s.\n", fn.c_str());
 }
 
@@ -154,6 +220,16 @@ int main(int argc, char **argv)
             v == "--doubly_unique_read_cnt_thres" || v == "--ilp_alpha" || v == "--ilp_epsilon" || v == "--ilp_max_cov" ||
             v == "--ilp_resolution") {   // fine parameters feed the ILP only (main.cpp:141-222)
             need(i, "Please specify a parameter value.\n"); continue;
+        }
+        if (v == "--fastq_stats") {   // diagnostic: parse one FASTQ like a query would, print a digest, exit
+            const char *f = need(i, "Please specify a fastq file.\n");
+            std::vector<uint8_t> b; std::vector<uint64_t> o;
+            read_fastq(f, min_rl, b, o);
+            uint64_t hsh = 1469598103934665603ull;
+            for (uint8_t c : b) hsh = (hsh ^ c) * 1099511628211ull;
+            for (uint64_t x : o) hsh = (hsh ^ x) * 1099511628211ull;
+            printf("reads %zu bases %zu fnv %016llx\n", o.size() - 1, b.size(), (unsigned long long)hsh);
+            return 0;
         }
         if (v == "--device") { device = atoi(need(i, "Please specify the GPU ordinal.\n")); continue; }
         if (v == "--dump_counts") { dump = need(i, "Please specify the counts file name.\n"); continue; }

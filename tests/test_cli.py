@@ -64,3 +64,57 @@ def test_cli_quantification_mode_and_dump(tmp_path):
     assert [int(x[3]) for x in gl] == e["cnt_u"][1:] and [int(x[4]) for x in gl] == e["cnt_d"][1:]
     ru = {int(x[2]): int(x[6]) for x in rows if x[0] == "L" and x[1] == "u"}
     assert ru == {i: v for i, v in enumerate(e["rcount_u"]) if v}
+
+
+def _py_fastq_digest(path, min_l=0):
+    """Independent parse: second line of every four, CR stripped, length filter, one
+    deterministic substitute base per read for all its N's (cammiq_main.cpp read_fastq)."""
+    M = (1 << 64) - 1
+    bases = bytearray()
+    offs = [0]
+    for rec, chunk in enumerate(_records(path)):
+        seq = chunk
+        if len(seq) < min_l:
+            continue
+        if b"N" in seq:
+            z = ((rec + 1) * 0x9E3779B97F4A7C15) & M
+            z ^= z >> 29
+            seq = seq.replace(b"N", b"ACGT"[(z >> 7) & 3:((z >> 7) & 3) + 1])
+        bases += seq
+        offs.append(len(bases))
+    h = 1469598103934665603
+    for c in bases:
+        h = ((h ^ c) * 1099511628211) & M
+    for x in offs:
+        h = ((h ^ x) * 1099511628211) & M
+    return len(offs) - 1, len(bases), h
+
+
+def _records(path):
+    lines = open(path, "rb").read().split(b"\n")
+    if lines and lines[-1] == b"":
+        lines.pop()
+    for i in range(1, len(lines), 4):
+        yield lines[i].rstrip(b"\r")
+
+
+@pytest.mark.parametrize("n_reads,crlf,final_newline", [(50, False, True), (50, True, False), (40000, False, True),
+                                                        (40000, True, False)])
+def test_fastq_loader_matches_independent_parse(tmp_path, n_reads, crlf, final_newline):
+    """Small files take the single-thread path, > 4 MiB files the multi-threaded mmap path."""
+    import numpy as np
+    rng = np.random.default_rng(n_reads + crlf)
+    nl = b"\r\n" if crlf else b"\n"
+    out = []
+    for i in range(n_reads):
+        L = int(rng.integers(20, 250))
+        s = np.frombuffer(b"ACGTN", np.uint8)[rng.choice(5, size=L, p=[.245, .245, .245, .245, .02])].tobytes()
+        out.append(b"@r%d" % i + nl + s + nl + b"+" + nl + b"I" * L)
+    data = nl.join(out) + (nl if final_newline else b"")
+    fq = tmp_path / "x.fastq"
+    fq.write_bytes(data)
+    for min_l in (0, 100):
+        r = _run(["--query", "--read_length_filter", str(min_l), "--fastq_stats", str(fq)])
+        assert r.returncode == 0, r.stderr
+        n, b, h = _py_fastq_digest(str(fq), min_l)
+        assert r.stdout.split() == ["reads", str(n), "bases", str(b), "fnv", "%016x" % h]
