@@ -245,3 +245,47 @@ def test_many_genomes_use_global_counters(tmp_path):
         assert_same(got, ref, f"G={G} mode={mode}", rcount=(mode == 0))
         assert got["pairs"] == ref["pairs"]
     assert int(ref["cnt_u"][remap[9]]) > 0
+
+
+def test_full_size_configs1_properties(tmp_path):
+    """BASELINE.json configs[1] at full size (500 genomes, ~49 M markers, 10 M x 100 bp reads):
+    far beyond the oracle, so check what must hold at any size -- every read lands in exactly
+    one outcome, halves add up to the whole (the multi-GPU contract), a repeated call gives the
+    same answer, the host API equals the device API -- plus the oracle on a 100 k-read slice."""
+    import torch
+    from cammiq_amd import bigsynth
+    G, n, rl = 500, 10_000_000, 100
+    w = bigsynth.World(seed=2, n_genomes=G, genome_len=3_450_000)
+    pu = str(tmp_path / "index_u.bin1")
+    nu, nd = w.write_index(pu, None)
+    assert nu > 45_000_000 and nd == 0
+    ix = cq.Index(pu, None, device=0)
+    b, o = w.reads(seed=1000, n=n, length=rl)
+    whole = ix.query(b, o, G)
+    assert whole["nskipped"] == 0
+    assert int(whole["cnt_u"].sum()) + whole["nundet"] + whole["nconf"] == n          # conservation (unique-only)
+    assert int(whole["rcount_u"].sum()) >= int(whole["cnt_u"].sum())                    # >= 1 leaf per counted read
+    again = ix.query(b, o, G)
+    assert_same(again, whole, "idempotence")
+    half = n // 2
+    a1 = ix.query(b[:half * rl], o[:half + 1], G)
+    a2 = ix.query(b[half * rl:], o[half:] - o[half], G)
+    for k in ("cnt_u", "cnt_d", "rcount_u"):
+        assert np.array_equal(a1[k] + a2[k], whole[k]), k
+    assert a1["nundet"] + a2["nundet"] == whole["nundet"] and a1["nconf"] + a2["nconf"] == whole["nconf"]
+    # device-resident API in one launch
+    packed, lens, sk = cq.pack_reads(b, o, ix.hash_len)
+    dp = torch.from_numpy(packed.view(np.int32)).cuda()
+    dl = torch.from_numpy(lens).cuda()
+    ctr = torch.zeros(ix.counter_words(G), dtype=torch.int64, device="cuda")
+    rc = torch.zeros(sum(ix.n_leaves), dtype=torch.int32, device="cuda")
+    ix.query_device(0, dp.data_ptr(), dl.data_ptr(), n, packed.shape[1], rl, G, ctr.data_ptr(), rc.data_ptr(),
+                    torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    c = ctr.cpu().numpy().astype(np.uint64)
+    assert np.array_equal(c[:G + 1], whole["cnt_u"]) and int(c[2 * G + 2]) == whole["nundet"]
+    assert np.array_equal(rc.cpu().numpy().view(np.uint32), whole["rcount_u"])
+    # and the oracle on a slice
+    ns = 100_000
+    ref = oracle_lib.OracleIndex(pu, None).query(b[:ns * rl], o[:ns + 1], G, nthreads=16)
+    assert_same(ix.query(b[:ns * rl], o[:ns + 1], G), ref, "slice vs oracle")
