@@ -54,6 +54,7 @@ struct cq_index {
     cq::DevIndex dev{};
     // per-handle workspace (grown on demand, reused across calls)
     uint32_t *d_ovf_list = nullptr, *d_ovf_count = nullptr;
+    uint64_t *d_stamps = nullptr;   // 8 words of their own for diagnostic (CQ_STAMPS) kernel builds
     uint64_t ovf_cap = 0;
     uint64_t *d_pair_keys = nullptr, *d_pair_cnts = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -82,6 +83,19 @@ void release_device(cq_index *ix)
     if (ix->d_leaf_rids) (void)hipFree(ix->d_leaf_rids);
     if (ix->d_ovf_list) (void)hipFree(ix->d_ovf_list);
     if (ix->d_ovf_count) (void)hipFree(ix->d_ovf_count);
+    if (ix->d_stamps) {
+        // diagnostic builds (-DCQ_STAMPS=1): per-phase cycle sums, dumped when the handle goes away
+        if (const char *f = getenv("CAMMIQ_STAMPS_FILE")) {
+            uint64_t v[8] = {0};
+            if (hipMemcpy(v, ix->d_stamps, sizeof v, hipMemcpyDeviceToHost) == hipSuccess)
+                if (FILE *fo = fopen(f, "w")) {
+                    fprintf(fo, "staging %llu\nprepass %llu\nprobe %llu\nlookup %llu\ndecide %llu\n", (unsigned long long)v[0],
+                            (unsigned long long)v[1], (unsigned long long)v[2], (unsigned long long)v[3], (unsigned long long)v[4]);
+                    fclose(fo);
+                }
+        }
+        (void)hipFree(ix->d_stamps);
+    }
     if (ix->d_pair_keys) (void)hipFree(ix->d_pair_keys);
     if (ix->d_pair_cnts) (void)hipFree(ix->d_pair_cnts);
     if (ix->ev0) (void)hipEventDestroy(ix->ev0);
@@ -125,6 +139,8 @@ int upload(cq_index *ix)
         if (nl) CQ_HIP(hipMemcpy(ix->d_leaf_rids, rr.data(), nl * sizeof(uint2), hipMemcpyHostToDevice));
     }
     CQ_HIP(hipMalloc((void **)&ix->d_ovf_count, sizeof(uint32_t)));
+    CQ_HIP(hipMalloc((void **)&ix->d_stamps, 8 * sizeof(uint64_t)));
+    CQ_HIP(hipMemset(ix->d_stamps, 0, 8 * sizeof(uint64_t)));
     CQ_HIP(hipMalloc((void **)&ix->d_pair_keys, (size_t)kPairCap * 8));
     CQ_HIP(hipMalloc((void **)&ix->d_pair_cnts, (size_t)kPairCap * 8));
     CQ_HIP(hipMemset(ix->d_pair_keys, 0xFF, (size_t)kPairCap * 8));
@@ -295,6 +311,7 @@ int cq_query_device(cq_index *ix, int mode, const uint32_t *d_packed, const uint
     a.pair_keys = ix->d_pair_keys;
     a.pair_cnts = ix->d_pair_cnts;
     a.pair_cap = kPairCap;
+    a.stamps = ix->d_stamps;   // only written by diagnostic (CQ_STAMPS) builds
     CQ_HIP(cq::launch_classify(ix->dev, a, ix->n_cus, st, ix->ev0, ix->ev1));
     ix->ev_valid = true;
     return CQ_OK;

@@ -41,6 +41,7 @@ struct QueryArgs {
     uint64_t *pair_keys;     // SC mode pair map (power-of-two capacity)
     uint64_t *pair_cnts;
     uint32_t pair_cap;
+    uint64_t *stamps;        // diagnostic builds only (CQ_STAMPS): per-phase cycle sums, else null
 };
 
 hipError_t launch_classify(const DevIndex &ix, QueryArgs a, int n_cus, hipStream_t stream,

@@ -41,6 +41,14 @@ namespace {
 
 constexpr int kBlock = 256;
 constexpr int kWaves = kBlock / 64;
+#ifndef CQ_STAMPS
+#define CQ_STAMPS 0   /* diagnostic build only: per-phase s_memtime sums go to a.stamps (own buffer) */
+#endif
+#if CQ_STAMPS
+#define CQ_STAMP(i) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); st_acc[i] += t_ - st_last; st_last = t_; } while (0)
+#else
+#define CQ_STAMP(i) do {} while (0)
+#endif
 #ifndef CQ_WORK_DRAIN
 #define CQ_WORK_DRAIN 64
 #endif
@@ -188,17 +196,16 @@ __device__ __forceinline__ uint32_t walk_trie(const DevIndex &ix, const uint32_t
     }
 }
 
-// Orders this wave's LDS traffic (hardware executes one wave's LDS ops in order; this keeps
-// the compiler from moving them across the hand-off between lanes).
+// Hand-off between lanes of ONE wave through LDS.  The hardware executes a wave's LDS
+// operations in order; the wait + compiler barrier keep hipcc from moving or caching LDS
+// accesses across the hand-off.  Deliberately NOT a fence: a fence also waits for the
+// wave's outstanding global loads and atomics (vmcnt), which have nothing to do with LDS.
 __device__ __forceinline__ void wave_sync()
 {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// Resolve one candidate: walk the trie below the bucket root (most codes are depth-0 leaves
-// already), fetch the leaf's refIDs, append to the read's hit list.
 // Append one hit (global leaf id + its refIDs) to the read's hit list.
 template <int CAP>
 __device__ __forceinline__ void append_hit(const Tile &t, uint32_t rl, uint32_t gid, uint32_t r1, uint32_t r2)
@@ -369,6 +376,7 @@ __device__ __forceinline__ void decide(const QueryArgs &a, const Tile &t, uint32
 template <int R, int CAP, bool SLOW>
 __global__ void __launch_bounds__(kBlock) classify_kernel(DevIndex ix, QueryArgs a)
 {
+    static_assert(SLOW || R * 4 <= 64, "a sub-tile's rows must fit one 16-byte load per lane");
     extern __shared__ __align__(16) uint32_t smem[];
     const uint32_t sw = a.stride_words, swp = sw + 2;
     const uint32_t G1 = a.n_genomes + 1;
@@ -399,19 +407,33 @@ __global__ void __launch_bounds__(kBlock) classify_kernel(DevIndex ix, QueryArgs
     const uint64_t n_sub = (n_reads + R - 1) / R;
     const uint64_t wave_gid = (uint64_t)blockIdx.x * kWaves + wave, n_waves = (uint64_t)gridDim.x * kWaves;
 
+    // rows + lengths of the NEXT sub-tile, requested one sub-tile ahead (fast path only)
+    uint4 pf_row = make_uint4(0, 0, 0, 0);
+    uint32_t pf_len = 0;
+    auto prefetch = [&](uint64_t sub) {
+        if (sub >= n_sub) return;
+        const uint64_t r0 = sub * R;
+        const uint32_t nr = (uint32_t)((n_reads - r0) < (uint64_t)R ? (n_reads - r0) : (uint64_t)R);
+        if (lane < nr * (sw >> 2)) pf_row = ((const uint4 *)(a.packed + r0 * sw))[lane];
+        if (lane < nr) pf_len = a.lens[r0 + lane];
+    };
+    if (!SLOW) prefetch(wave_gid);
+#if CQ_STAMPS
+    unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0}, st_last;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last) :: "memory");
+#endif
     for (uint64_t sub = wave_gid; sub < n_sub; sub += n_waves) {
         const uint64_t r0 = sub * R;
         const uint32_t nr = (uint32_t)((n_reads - r0) < (uint64_t)R ? (n_reads - r0) : (uint64_t)R);
 
-        // ---- stage the sub-tile: 2-bit rows -> LDS (16 B per lane, contiguous when direct)
+        // ---- stage the sub-tile: 2-bit rows -> LDS.  The fast path fetched them one sub-tile
+        // ahead (16 B per lane, contiguous: R reads x <= 4 vectors fit one wave instruction).
         if (!SLOW) {
-            const uint4 *src = (const uint4 *)(a.packed + r0 * sw);
             const uint32_t nvec = nr * (sw >> 2);
-            for (uint32_t i = lane; i < nvec; i += 64) {
-                const uint4 v = src[i];
-                const uint32_t w = i * 4, rl = div_small(w, sw, a.magic_s), c = w - __umul24(rl, sw);
+            if (lane < nvec) {
+                const uint32_t w = lane * 4, rl = div_small(w, sw, a.magic_s), c = w - __umul24(rl, sw);
                 uint32_t *dst = t.rows + rl * swp + c;
-                dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+                dst[0] = pf_row.x; dst[1] = pf_row.y; dst[2] = pf_row.z; dst[3] = pf_row.w;
             }
         } else {
             for (uint32_t i = lane; i < nr * sw; i += 64) {
@@ -421,12 +443,14 @@ __global__ void __launch_bounds__(kBlock) classify_kernel(DevIndex ix, QueryArgs
         }
         if (lane < (uint32_t)R) {
             uint32_t len = 0;
-            if (lane < nr) len = SLOW ? a.lens[a.ovf_list[r0 + lane]] : a.lens[r0 + lane];
+            if (lane < nr) len = SLOW ? a.lens[a.ovf_list[r0 + lane]] : pf_len;
             t.len[lane] = len;
             t.hitcnt[lane] = 0;
             t.rows[lane * swp + sw] = 0; t.rows[lane * swp + sw + 1] = 0;   // pad words read by the window extract
         }
+        if (!SLOW) prefetch(sub + n_waves);   // in flight while this sub-tile is processed
         wave_sync();
+        CQ_STAMP(0);   // staging
 
         // ---- pre-pass: hash the canonical m-mer at every base position, once.  A lane takes
         // two adjacent positions: they share the index arithmetic and the row words.
@@ -446,6 +470,7 @@ __global__ void __launch_bounds__(kBlock) classify_kernel(DevIndex ix, QueryArgs
             }
         }
         wave_sync();
+        CQ_STAMP(1);   // pre-pass
 
         // ---- probe phase: lane = (read, window).  The hot loop only DETECTS: it reads the
         // window's bucket and compares the low 32 key bits of the four slots with the low
@@ -508,10 +533,12 @@ __global__ void __launch_bounds__(kBlock) classify_kernel(DevIndex ix, QueryArgs
                                                                __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
                 if (flag) t.work[nw + off] = make_uint2(b, rl | (pw << 8));
                 nw += (uint32_t)__popcll(mask);
-                if (nw >= (uint32_t)kWorkDrain) { drain_work<CAP>(ix, t, swp, nw); nw = 0; }
+                if (nw >= (uint32_t)kWorkDrain) { CQ_STAMP(2); drain_work<CAP>(ix, t, swp, nw); nw = 0; CQ_STAMP(3); }
             }
         }
+        CQ_STAMP(2);   // probe loop
         if (nw) drain_work<CAP>(ix, t, swp, nw);
+        CQ_STAMP(3);   // exact lookups
         wave_sync();
 
         // ---- decision phase: one lane per read
@@ -530,7 +557,12 @@ __global__ void __launch_bounds__(kBlock) classify_kernel(DevIndex ix, QueryArgs
             }
         }
         wave_sync();   // hit lists fully consumed before the next sub-tile resets them
+        CQ_STAMP(4);   // decision
     }
+#if CQ_STAMPS
+    if (!SLOW && lane == 0 && a.stamps)
+        for (int i = 0; i < 5; i++) atomicAdd((unsigned long long *)&a.stamps[i], st_acc[i]);
+#endif
 
     // ---- flush workgroup-level counters
     __syncthreads();
