@@ -8,7 +8,8 @@
 One "step" = one pass of the hot path (what FqReader::query64mt_p does for one FASTQ,
 /root/reference/src/query.cpp:650-889) over one batch of synthetic reads that is already
 resident in HBM: reset counters, classify kernel(s), and for N > 1 the RCCL all-reduce of the
-count vectors.  Index load / layout and FASTQ parsing are outside the bracket, exactly like
+count vectors (issued asynchronously: it overlaps the next step's kernel, all of them are
+complete before the clock stops).  Index load / layout and FASTQ parsing are outside the bracket, exactly like
 the reference's own `Time for query` line (query.cpp:459,645-647).
 
 Workload at N = 1 = BASELINE.json configs[1]: 500 synthetic bacterial-size genomes, --unique
@@ -73,10 +74,18 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the classify path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    # Rehearsal knob for a one-GPU box: CAMMIQ_BENCH_REHEARSAL=1 maps every rank to cuda:0 and uses
+    # gloo, so that the N > 1 code path (sharding, shared index files, all-reduce, max over ranks) can
+    # be exercised without an 8-GPU node.  Never set by the driver; numbers from it mean nothing.
+    rehearsal = os.environ.get("CAMMIQ_BENCH_REHEARSAL") == "1"
+    dev = 0 if rehearsal else local_rank
+    torch.cuda.set_device(dev)
     if world > 1:
         import torch.distributed as tdist
-        tdist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            tdist.init_process_group("gloo")
+        else:
+            tdist.init_process_group("nccl", device_id=torch.device("cuda", dev))
 
     h = k = 26
     G = args.genomes
@@ -100,7 +109,7 @@ def main():
         nu, nd = (int(x) for x in open(os.path.join(wdir, "leaves.txt")).read().split())
         t_gen = time.time() - t_setup
         t0 = time.time()
-        ix = cq.Index(pu, pd, device=local_rank)
+        ix = cq.Index(pu, pd, device=dev)
         t_load = time.time() - t0
         info = ix.info_dict()
 
@@ -112,19 +121,35 @@ def main():
         sw = packed.shape[1]
         d_packed = torch.from_numpy(packed.view(np.int32)).cuda()
         d_lens = torch.from_numpy(lens).cuda()
-        ctr = torch.zeros(ix.counter_words(G), dtype=torch.int64, device="cuda")
-        rc = torch.zeros(max(nu + nd, 1), dtype=torch.int32, device="cuda")
+        # two sets of counters: the all-reduce of step i overlaps the classify kernel of step i+1
+        # (independent batches, like consecutive FASTQ files of one run)
+        ctrs = [torch.zeros(ix.counter_words(G), dtype=torch.int64, device="cuda") for _ in range(2)]
+        rcs = [torch.zeros(max(nu + nd, 1), dtype=torch.int32, device="cuda") for _ in range(2)]
+        pending = [None, None]
         stream = torch.cuda.current_stream().cuda_stream
+        step_no = [0]
 
         def step():
-            ctr.zero_()                       # resetCounters (query.cpp:1820-1840)
-            rc.zero_()
+            b = step_no[0] & 1
+            step_no[0] += 1
+            if pending[b] is not None:
+                for wk in pending[b]:
+                    wk.wait()                 # the collective that last used this buffer pair
+                pending[b] = None
+            ctrs[b].zero_()                   # resetCounters (query.cpp:1820-1840)
+            rcs[b].zero_()
             ix.query_device(cq.MODE_P, d_packed.data_ptr(), d_lens.data_ptr(), n, sw, args.read_len, G,
-                            ctr.data_ptr(), rc.data_ptr(), stream)
+                            ctrs[b].data_ptr(), rcs[b].data_ptr(), stream)
             if world > 1:
-                cqdist.allreduce_counts(ctr, rc)
+                pending[b] = cqdist.allreduce_counts(ctrs[b], rcs[b], async_op=True)
+            return b
 
         def fence():
+            for b in (0, 1):
+                if pending[b] is not None:
+                    for wk in pending[b]:
+                        wk.wait()
+                    pending[b] = None
             if world > 1:
                 tdist.barrier()
             torch.cuda.synchronize()
@@ -133,16 +158,18 @@ def main():
             step()
         fence()
         kms = []
+        last = 0
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            step()
+            last = step()
             kms.append(ix.last_kernel_ms())   # HIP events on the launch stream, recorded inside the library
         fence()
         dt = time.perf_counter() - t0
         if world > 1:
-            tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
             tdist.all_reduce(tmax, op=tdist.ReduceOp.MAX)
             dt = float(tmax.item())
+        ctr = ctrs[last]
 
         # ---- sanity on the last step's counters: every read lands in exactly one outcome
         c = ctr.cpu().numpy().astype(np.uint64)
@@ -160,7 +187,9 @@ def main():
             achieved = n * B / (k_ms * 1e-3) / 1e9
             traffic = None
             tp = os.path.join(ROOT, "profiles", "traffic.json")
-            if os.path.exists(tp):
+            default_workload = (G == 500 and n == 10_000_000 and args.read_len == 100 and not args.both
+                                and args.genome_len == 3_450_000)
+            if default_workload and os.path.exists(tp):   # the PMC passes were made on exactly this workload
                 try:
                     traffic = json.load(open(tp)).get("hbm_bytes_per_launch")
                 except Exception:
@@ -179,7 +208,7 @@ def main():
                            "index_device_GB": round(info["device_bytes"] / 1e9, 3),
                            "table_buckets_overflowed": info["n_overflowed"], "table_max_chain": info["max_chain"],
                            "parallelism": f"reads sharded x{world}, index replicated" +
-                                          (", RCCL all-reduce of counts + rcount per step" if world > 1 else "")},
+                                          (", RCCL all-reduce of counts + rcount per step, overlapped with the next step's kernel" if world > 1 else "")},
                 "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                              "kernel": "classify_kernel<8,16,false>", "kernel_ms": round(k_ms, 4),

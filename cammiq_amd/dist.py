@@ -22,11 +22,15 @@ def shard_range(n_reads: int, rank: int, world: int) -> Tuple[int, int]:
     return n_reads * rank // world, n_reads * (rank + 1) // world
 
 
-def allreduce_counts(counters, rcount=None, group=None):
-    """Sum the per-rank counter block (and per-leaf rcount) over all ranks, in place."""
+def allreduce_counts(counters, rcount=None, group=None, async_op=False):
+    """Sum the per-rank counter block (and per-leaf rcount) over all ranks, in place.
+
+    With ``async_op=True`` returns the list of work handles (``.wait()`` them before touching the
+    tensors again): the collective then runs beside the next batch's classify kernel."""
     import torch.distributed as tdist
     if not tdist.is_initialized() or tdist.get_world_size(group) == 1:
-        return
-    tdist.all_reduce(counters, op=tdist.ReduceOp.SUM, group=group)
+        return []
+    works = [tdist.all_reduce(counters, op=tdist.ReduceOp.SUM, group=group, async_op=async_op)]
     if rcount is not None and rcount.numel():
-        tdist.all_reduce(rcount, op=tdist.ReduceOp.SUM, group=group)
+        works.append(tdist.all_reduce(rcount, op=tdist.ReduceOp.SUM, group=group, async_op=async_op))
+    return works if async_op else []
