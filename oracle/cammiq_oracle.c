@@ -582,7 +582,38 @@ static void cqo_classify_read(const cqo_index *ix, int mode, const uint8_t *read
     }
 
     /* Apply.  query64_sc never touches rcount (query.cpp:891-1080). */
-    if (locked) {
+    if (locked == 2) {
+        /* "fair" CPU variant for the reported baseline: same per-read work, but the
+         * counters are bumped with atomics instead of one global critical section, so the threads
+         * do not serialise on every read the way query64mt_p does. */
+        if (d_nundet) {
+#pragma omp atomic
+            acc->nundet += 1;
+        }
+        if (d_nconf) {
+#pragma omp atomic
+            acc->nconf += 1;
+        }
+        for (int k = 0; k < n_inc_u; k++) {
+#pragma omp atomic
+            acc->cnt_u[inc_u[k]] += 1;
+        }
+        for (int k = 0; k < n_inc_d; k++) {
+#pragma omp atomic
+            acc->cnt_d[inc_d[k]] += 1;
+        }
+        if (bump && mode == CQO_MODE_P)
+            for (int k = 0; k < np; k++) {
+#pragma omp atomic
+                pnodes[k]->rcount += 1;
+            }
+        if (add_pb && mode == CQO_MODE_SC) {
+#pragma omp critical
+            cqo_pb_add(acc, rid_pairs[0]);
+        }
+#pragma omp atomic
+        acc->branch[br] += 1;
+    } else if (locked) {
 #pragma omp critical
         {
             acc->nundet += (uint64_t)d_nundet; acc->nconf += (uint64_t)d_nconf;
@@ -621,7 +652,8 @@ static int64_t cqo_check_reads(const cqo_index *ix, const uint8_t *bases, const 
  * one file after resetCounters (query.cpp:1820-1840).
  *   mode        CQO_MODE_P (query64_p / query64mt_p) or CQO_MODE_SC (query64_sc)
  *   nthreads    1 -> serial body (query64_p); >1 -> OpenMP over reads with one
- *               global critical section per update, as query64mt_p does.
+ *               global critical section per update, as query64mt_p does; <0 -> |nthreads|
+ *               threads with atomic counter updates (fair CPU variant for bench.py).
  *   cnt_u/cnt_d [n_genomes+1]; rcount_u/rcount_d per leaf in decode order;
  *   scal[0]=nundet scal[1]=nconf; branch[8]; pair_* (SC): up to pair_cap triples,
  *   *n_pairs receives the number of distinct pairs.
@@ -648,16 +680,19 @@ int64_t cqo_query(cqo_index *ix, int mode, int nthreads,
     for (int t = 0; t < 2; t++)
         for (uint64_t i = 0; i < ix->ht[t].leaf_cnt; i++) ix->ht[t].leaves[i]->rcount = 0;
 
-    if (nthreads <= 1) {
+    if (nthreads >= 0 && nthreads <= 1) {
         for (uint64_t r = 0; r < n_reads; r++)
             cqo_classify_read(ix, mode, bases + offsets[r], (size_t)(offsets[r + 1] - offsets[r]), &acc, 0);
     } else {
+        /* nthreads > 1: one global critical section per update, as query64mt_p does;
+         * nthreads < 0: |nthreads| threads with atomic counter updates (fair CPU variant). */
+        const int lock_mode = nthreads < 0 ? 2 : 1;
 #ifdef _OPENMP
-        omp_set_num_threads(nthreads);
+        omp_set_num_threads(nthreads < 0 ? -nthreads : nthreads);
 #endif
 #pragma omp parallel for
         for (int64_t r = 0; r < (int64_t)n_reads; r++)
-            cqo_classify_read(ix, mode, bases + offsets[r], (size_t)(offsets[r + 1] - offsets[r]), &acc, 1);
+            cqo_classify_read(ix, mode, bases + offsets[r], (size_t)(offsets[r + 1] - offsets[r]), &acc, lock_mode);
     }
 
     if (rcount_u) for (uint64_t i = 0; i < ix->ht[0].leaf_cnt; i++) rcount_u[i] = ix->ht[0].leaves[i]->rcount;

@@ -18,7 +18,7 @@ def test_oracle_matches_golden(name):
     ix = oracle_lib.OracleIndex(g["pu"], g["pd"])
     assert ix.hash_len == g["exp"]["hash_len"] and ix.n_leaves == g["exp"]["n_leaves"]
     b, o = synth.concat_reads(g["reads"])
-    for threads in (1, 3):
+    for threads in (1, 3, -3):       # serial, query64mt_p-style lock, atomic-counter variant
         got = ix.query(b, o, g["G"], mode=0, nthreads=threads)
         assert_same(got, g["exp"]["p"], f"{name} t={threads}")
         assert got["branch"] == g["exp"]["p"]["branch"]
