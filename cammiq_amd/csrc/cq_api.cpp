@@ -45,6 +45,7 @@ struct cq_index {
     cq::DecodedTable tab[2];
     cq::FlatImage img;
     uint64_t n_file_buckets[2] = {0, 0};
+    uint64_t n_trie_nodes = 0;
     uint32_t doubly_flag[2] = {0, 1};
     int device = CQ_DEVICE_NONE;
     int n_cus = 0;
@@ -218,6 +219,12 @@ int cq_index_load(const char *path_u, const char *path_d, int device, cq_index *
     if (device >= 0) {
         int rc = upload(ix);
         if (rc != CQ_OK) { release_device(ix); delete ix; return rc; }
+        // the image now lives in HBM: drop the host copy (cq_index_probe needs a CQ_DEVICE_NONE handle)
+        ix->n_trie_nodes = ix->img.nodes.size() - 1;
+        std::vector<uint32_t>().swap(ix->img.table);
+        std::vector<cq::Node>().swap(ix->img.nodes);
+        std::vector<uint32_t>().swap(ix->img.leaf_r1);
+        std::vector<uint32_t>().swap(ix->img.leaf_r2);
     }
     *out = ix;
     return CQ_OK;
@@ -236,7 +243,7 @@ int cq_index_get_info(const cq_index *ix, cq_index_info *info)
         info->n_leaves[t] = ix->img.n_leaves[t];
         info->n_file_buckets[t] = ix->n_file_buckets[t];
     }
-    info->n_trie_nodes = ix->img.nodes.size() - 1;
+    info->n_trie_nodes = ix->img.nodes.empty() ? ix->n_trie_nodes : ix->img.nodes.size() - 1;
     info->n_keys = ix->img.n_keys;
     info->n_table_buckets = ix->img.n_buckets_alloc;
     info->n_overflowed = ix->img.n_overflowed;
