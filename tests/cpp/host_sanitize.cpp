@@ -1,0 +1,53 @@
+// host_sanitize.cpp -- ASAN/UBSAN driver for the host-side code of libcammiq_hip.so that needs no GPU:
+// decoder, layout builder (incl. path compression and the host mirror of the device lookup) and packer.
+// Built and run by tests/test_sanitize.py:
+//   g++ -std=c++17 -O1 -g -fsanitize=address,undefined -fno-sanitize-recover=all ...
+// usage: host_sanitize index_u.bin1 [index_d.bin2|-] reads.txt
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <string>
+#include <vector>
+
+#include "../../cammiq_amd/csrc/cq_index.hpp"
+
+int main(int argc, char **argv)
+{
+    if (argc < 4) return 2;
+    cq::DecodedTable u, d;
+    std::string err;
+    int rc = cq::decode_table(argv[1], u, err);
+    if (rc != CQ_OK) { printf("decode_u %d %s\n", rc, err.c_str()); return 0; }   // a clean error is a pass
+    if (strcmp(argv[2], "-") != 0) {
+        rc = cq::decode_table(argv[2], d, err);
+        if (rc != CQ_OK) { printf("decode_d %d %s\n", rc, err.c_str()); return 0; }
+    } else cq::make_empty_table(u.hash_len, d);
+    cq::FlatImage img;
+    rc = cq::build_image(u, d, 0.0, img, err);
+    if (rc != CQ_OK) { printf("layout %d %s\n", rc, err.c_str()); return 0; }
+    // every bucket key must be found again, with a sane chain length
+    uint64_t found = 0;
+    for (const cq::DecodedTable *t : {&u, &d})
+        for (uint64_t k : t->bucket_key) {
+            uint32_t vu, vd, chain;
+            cq::image_lookup(img, k, vu, vd, &chain);
+            if ((vu | vd) == 0 || chain > img.max_chain) { printf("LOOKUP FAILED\n"); return 1; }
+            found++;
+        }
+    // pack the reads (one per line; anything goes)
+    std::ifstream in(argv[3], std::ios::binary);
+    std::vector<uint8_t> bases;
+    std::vector<uint64_t> offs(1, 0);
+    std::string line;
+    while (std::getline(in, line)) { bases.insert(bases.end(), line.begin(), line.end()); offs.push_back(bases.size()); }
+    const uint64_t n = offs.size() - 1;
+    const uint32_t sw = cq_pack_stride_words(255);
+    std::vector<uint32_t> packed(n * sw + 1);
+    std::vector<uint8_t> lens(n + 1);
+    uint64_t sk = 0;
+    rc = cq_pack_reads(bases.data(), offs.data(), n, img.hash_len, sw, packed.data(), lens.data(), &sk);
+    printf("ok leaves %zu+%zu keys %llu nodes %zu found %llu reads %llu skipped %llu rc %d\n", u.leaves.size(), d.leaves.size(),
+           (unsigned long long)img.n_keys, img.nodes.size(), (unsigned long long)found, (unsigned long long)n,
+           (unsigned long long)sk, rc);
+    return 0;
+}
