@@ -126,13 +126,13 @@ int upload(cq_index *ix)
     CQ_HIP(hipGetDeviceProperties(&prop, ix->device));
     ix->n_cus = prop.multiProcessorCount;
     const cq::FlatImage &img = ix->img;
-    const size_t sb = img.table.size() * sizeof(uint32_t);
+    const size_t sb = img.table_words * sizeof(uint32_t);
     const size_t nb = img.nodes.size() * sizeof(cq::Node);
     const size_t nl = img.leaf_r1.size();
     CQ_HIP(hipMalloc(&ix->d_slots, sb));
     CQ_HIP(hipMalloc(&ix->d_nodes, nb));
     CQ_HIP(hipMalloc(&ix->d_leaf_rids, std::max<size_t>(nl, 1) * sizeof(uint2)));
-    CQ_HIP(hipMemcpy(ix->d_slots, img.table.data(), sb, hipMemcpyHostToDevice));
+    CQ_HIP(hipMemcpy(ix->d_slots, img.table.get(), sb, hipMemcpyHostToDevice));
     CQ_HIP(hipMemcpy(ix->d_nodes, img.nodes.data(), nb, hipMemcpyHostToDevice));
     {
         std::vector<uint2> rr(nl);
@@ -221,7 +221,7 @@ int cq_index_load(const char *path_u, const char *path_d, int device, cq_index *
         if (rc != CQ_OK) { release_device(ix); delete ix; return rc; }
         // the image now lives in HBM: drop the host copy (cq_index_probe needs a CQ_DEVICE_NONE handle)
         ix->n_trie_nodes = ix->img.nodes.size() - 1;
-        std::vector<uint32_t>().swap(ix->img.table);
+        ix->img.table.reset();
         std::vector<cq::Node>().swap(ix->img.nodes);
         std::vector<uint32_t>().swap(ix->img.leaf_r1);
         std::vector<uint32_t>().swap(ix->img.leaf_r2);
@@ -263,7 +263,7 @@ int cq_index_leaves(const cq_index *ix, int table, cq_leaf *out)
 int cq_index_probe(const cq_index *ix, uint64_t hv, uint32_t *code_u, uint32_t *code_d, uint32_t *chain)
 {
     if (!ix || !code_u || !code_d) return fail(CQ_ERR_ARG, "cq_index_probe: NULL argument");
-    if (ix->img.table.empty()) return fail(CQ_ERR_ARG, "cq_index_probe: host image was released");
+    if (!ix->img.table) return fail(CQ_ERR_ARG, "cq_index_probe: host image was released");
     cq::image_lookup(ix->img, hv, *code_u, *code_d, chain);
     return CQ_OK;
 }

@@ -12,6 +12,7 @@
 #define CQ_INDEX_HPP_
 
 #include <cstdint>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -43,7 +44,10 @@ struct FlatImage {
     uint64_t n_overflowed = 0;
     uint32_t max_chain = 1;
     uint32_t max_refid = 0;
-    std::vector<uint32_t> table;  // CQ_BUCKET_WORDS words per bucket (layout in cq_device.h)
+    // CQ_BUCKET_WORDS words per bucket (layout in cq_device.h).  Not a std::vector: a multi-GB table
+    // is allocated uninitialised and first touched by all cores at once.
+    std::unique_ptr<uint32_t[]> table;
+    size_t table_words = 0;
     std::vector<Node> nodes;      // linked: d-table indices/leaf ids already offset
     std::vector<uint32_t> leaf_r1, leaf_r2;  // global leaf id -> refIDs (u leaves first)
 };

@@ -187,12 +187,28 @@ int build_image(const DecodedTable &u, const DecodedTable &d, double keys_per_bu
     img.n_buckets = nbk;
     const uint32_t n_buckets = (uint32_t)nbk;
 
-    std::vector<Entry> ent;
-    ent.reserve(nb_u + nb_d);
+    std::vector<Entry> ent(nb_u + nb_d);
+    // trie codes first (path compression appends to one node array: sequential) ...
     for (uint64_t i = 0; i < nb_u; i++)
-        ent.push_back(Entry{cq_home_bucket(u.bucket_key[i], img.hash_len, n_buckets), (uint32_t)i, u.bucket_key[i], comp.run(u.bucket_code[i]), 0});
+        ent[i] = Entry{0, (uint32_t)i, u.bucket_key[i], comp.run(u.bucket_code[i]), 0};
     for (uint64_t i = 0; i < nb_d; i++)
-        ent.push_back(Entry{cq_home_bucket(d.bucket_key[i], img.hash_len, n_buckets), (uint32_t)i, d.bucket_key[i], 0, comp.run(relink_d(d.bucket_code[i]))});
+        ent[nb_u + i] = Entry{0, (uint32_t)i, d.bucket_key[i], 0, comp.run(relink_d(d.bucket_code[i]))};
+    // ... then the home buckets (a minimizer scan per key: the expensive part) on all cores
+    {
+        unsigned hw = std::thread::hardware_concurrency();
+        const unsigned nt = ent.size() < (1u << 16) ? 1u : std::max(1u, std::min(hw ? hw : 1u, 32u));
+        const uint32_t hl = img.hash_len;
+        auto work = [&](unsigned t) {
+            const size_t lo = ent.size() * t / nt, hi = ent.size() * (t + 1) / nt;
+            for (size_t i = lo; i < hi; i++) ent[i].home = cq_home_bucket(ent[i].key, hl, n_buckets);
+        };
+        if (nt == 1) work(0);
+        else {
+            std::vector<std::thread> th;
+            for (unsigned t = 0; t < nt; t++) th.emplace_back(work, t);
+            for (auto &x : th) x.join();
+        }
+    }
     if (img.nodes.size() >= (1ull << 30)) { err = "more than 2^30 trie nodes after path compression"; return CQ_ERR_LIMIT; }
     std::vector<Node>().swap(linked);
     sort_entries(ent, n_buckets);
@@ -223,11 +239,28 @@ int build_image(const DecodedTable &u, const DecodedTable &d, double keys_per_bu
 
     // ---- linear sweep placement
     img.n_buckets_alloc = nbk + CQ_SPILL_TAIL;
-    img.table.assign(img.n_buckets_alloc * CQ_BUCKET_WORDS, 0u);
-    for (uint64_t b = 0; b < img.n_buckets_alloc; b++) {
-        uint32_t *bw = &img.table[b * CQ_BUCKET_WORDS];
-        for (int k = 0; k < CQ_SLOTS_PER_BUCKET; k++) bw[CQ_BW_KEY_LO + k] = bw[CQ_BW_KEY_HI + k] = 0xFFFFFFFFu;
-        bw[CQ_BW_KEY_LO] = 0xFFFFFFFEu;   // empty slot 0: overflow flag (bit 0) must read 0
+    img.table_words = img.n_buckets_alloc * CQ_BUCKET_WORDS;
+    img.table.reset(new uint32_t[img.table_words]);   // uninitialised: the threads below first-touch it
+    {
+        unsigned hw = std::thread::hardware_concurrency();
+        const unsigned nt = img.n_buckets_alloc < (1u << 16) ? 1u : std::max(1u, std::min(hw ? hw : 1u, 32u));
+        auto init = [&](unsigned t) {
+            const uint64_t lo = img.n_buckets_alloc * t / nt, hi = img.n_buckets_alloc * (t + 1) / nt;
+            for (uint64_t b = lo; b < hi; b++) {
+                uint32_t *bw = &img.table[b * CQ_BUCKET_WORDS];
+                for (int k = 0; k < CQ_SLOTS_PER_BUCKET; k++) {
+                    bw[CQ_BW_KEY_LO + k] = bw[CQ_BW_KEY_HI + k] = 0xFFFFFFFFu;
+                    bw[CQ_BW_VAL_U + k] = bw[CQ_BW_VAL_D + k] = 0u;
+                }
+                bw[CQ_BW_KEY_LO] = 0xFFFFFFFEu;   // empty slot 0: overflow flag (bit 0) must read 0
+            }
+        };
+        if (nt == 1) init(0);
+        else {
+            std::vector<std::thread> th;
+            for (unsigned t = 0; t < nt; t++) th.emplace_back(init, t);
+            for (auto &x : th) x.join();
+        }
     }
     size_t next = 0;         // next entry not yet pulled into the carry
     size_t carry_lo = 0;     // entries [carry_lo, next) are waiting for a slot, oldest first
