@@ -10,7 +10,7 @@
 //   the ILP        runILP_* needs CPLEX/Gurobi; with --dump_counts FILE this shell writes
 //                  everything the unmodified ILP consumes (per-genome counts, per-leaf rcount
 //                  in map_sp order) so a host with a solver can pick it up.
-// Extensions (not in the reference): --device N, --dump_counts FILE, missing .bin2 allowed.
+// Extensions (not in the reference): --device N, --dump_counts FILE, --image_cache, missing .bin2 allowed.
 #include <dirent.h>
 #include <fcntl.h>
 #include <sys/mman.h>
@@ -232,6 +232,7 @@ int main(int argc, char **argv)
             return 0;
         }
         if (v == "--device") { device = atoi(need(i, "Please specify the GPU ordinal.\n")); continue; }
+        if (v == "--image_cache") { setenv("CAMMIQ_IMAGE_CACHE", "1", 1); continue; }   // see cq_cache.cpp
         if (v == "--dump_counts") { dump = need(i, "Please specify the counts file name.\n"); continue; }
         if (v == "-h") {
             need(i, "Please specify the hash length.\n");

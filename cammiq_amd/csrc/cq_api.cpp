@@ -46,6 +46,7 @@ struct cq_index {
     cq::FlatImage img;
     uint64_t n_file_buckets[2] = {0, 0};
     uint64_t n_trie_nodes = 0;
+    bool from_cache = false;
     uint32_t doubly_flag[2] = {0, 1};
     int device = CQ_DEVICE_NONE;
     int n_cus = 0;
@@ -173,10 +174,26 @@ int cq_index_load(const char *path_u, const char *path_d, int device, cq_index *
     cq_index *ix = new (std::nothrow) cq_index();
     if (!ix) return fail(CQ_ERR_NOMEM, "out of memory");
     const bool have_d = path_d && path_d[0];
+    // device-memory budget for the table: at most half of what is free
+    double budget = 1e30;
+    if (device >= 0) {
+        size_t free_b = 0, total_b = 0;
+        if (hipSetDevice(device) == hipSuccess && hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b)
+            budget = 0.5 * (double)free_b;
+    }
+    // Optional image cache next to index_u (cq_cache.cpp); the .bin files stay authoritative.
+    const char *ce = getenv("CAMMIQ_IMAGE_CACHE");
+    const bool use_cache = ce && ce[0] == '1';
+    const std::string cache_file = std::string(path_u) + ".cqimg";
+    cq::SourceStamp stamp;
+    const bool stamped = use_cache && cq::stamp_sources(path_u, have_d ? path_d : "", stamp);
+    bool from_cache = false;
+    if (stamped && !getenv("CAMMIQ_KEYS_PER_BUCKET"))
+        from_cache = cq::load_image(cache_file, stamp, budget >= 1e29 ? ~0ull : (uint64_t)budget, ix->tab, ix->img);
     // The reference loads the two files on two pthreads (query.cpp:112-116); same here.
     int rc_u = CQ_OK, rc_d = CQ_OK;
     std::string err_u, err_d;
-    try {
+    if (!from_cache) try {
         std::thread td;
         if (have_d) td = std::thread([&] { rc_d = cq::decode_table(path_d, ix->tab[1], err_d); });
         rc_u = cq::decode_table(path_u, ix->tab[0], err_u);
@@ -184,24 +201,14 @@ int cq_index_load(const char *path_u, const char *path_d, int device, cq_index *
         if (rc_u != CQ_OK) { delete ix; return fail(rc_u, err_u); }
         if (rc_d != CQ_OK) { delete ix; return fail(rc_d, err_d); }
         if (!have_d) cq::make_empty_table(ix->tab[0].hash_len, ix->tab[1]);
-        for (int t = 0; t < 2; t++) {
-            ix->n_file_buckets[t] = ix->tab[t].n_file_buckets;
-            ix->doubly_flag[t] = ix->tab[t].doubly;
-        }
         std::string err;
         // Average keys per 4-slot bucket of the device table.  Emptier tables overflow less
         // (fewer windows take the exact path): 1.0 costs 64 B of HBM per key (measured: 0.5 -> +2 %,
         // 1.5 -> -3 %); when the table would not fit comfortably it is packed tighter.
         // CAMMIQ_KEYS_PER_BUCKET overrides (tuning knob, not part of the ABI).
         double kpb = 1.0;
-        if (device >= 0) {
-            size_t free_b = 0, total_b = 0;
-            if (hipSetDevice(device) == hipSuccess && hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b) {
-                const double keys = (double)(ix->tab[0].bucket_key.size() + ix->tab[1].bucket_key.size());
-                const double budget = 0.5 * (double)free_b;
-                if (keys / kpb * 64.0 > budget) kpb = std::min(3.2, keys * 64.0 / budget);
-            }
-        }
+        const double keys = (double)(ix->tab[0].bucket_key.size() + ix->tab[1].bucket_key.size());
+        if (keys / kpb * 64.0 > budget) kpb = std::min(3.2, keys * 64.0 / budget);
         if (const char *e = getenv("CAMMIQ_KEYS_PER_BUCKET")) kpb = atof(e);
         int rc = cq::build_image(ix->tab[0], ix->tab[1], kpb, ix->img, err);
         if (rc != CQ_OK) { delete ix; return fail(rc, err); }
@@ -211,10 +218,16 @@ int cq_index_load(const char *path_u, const char *path_d, int device, cq_index *
             std::vector<uint32_t>().swap(ix->tab[t].bucket_code);
             std::vector<cq::Node>().swap(ix->tab[t].nodes);
         }
+        if (stamped && !getenv("CAMMIQ_KEYS_PER_BUCKET")) (void)cq::save_image(cache_file, stamp, ix->tab, ix->img);
     } catch (const std::bad_alloc &) {
         delete ix;
         return fail(CQ_ERR_NOMEM, "out of memory while loading the index");
     }
+    for (int t = 0; t < 2; t++) {
+        ix->n_file_buckets[t] = ix->tab[t].n_file_buckets;
+        ix->doubly_flag[t] = ix->tab[t].doubly;
+    }
+    ix->from_cache = from_cache;
     ix->device = device;
     if (device >= 0) {
         int rc = upload(ix);
@@ -249,6 +262,7 @@ int cq_index_get_info(const cq_index *ix, cq_index_info *info)
     info->n_overflowed = ix->img.n_overflowed;
     info->max_chain = ix->img.max_chain;
     info->device_bytes = ix->device_bytes;
+    info->reserved_ = ix->from_cache ? 1u : 0u;
     return CQ_OK;
 }
 

@@ -79,7 +79,7 @@ typedef struct cq_index_info {
     uint64_t n_table_buckets;  /* 64-byte buckets in the device table (incl. spill tail) */
     uint64_t n_overflowed;     /* buckets whose overflow bit is set */
     uint32_t max_chain;        /* longest bucket chain a lookup can walk */
-    uint32_t reserved_;
+    uint32_t reserved_;        /* 1 when the image came from the CAMMIQ_IMAGE_CACHE=1 file "<path_u>.cqimg" */
     uint64_t device_bytes;     /* HBM held by this handle */
 } cq_index_info;
 

@@ -36,6 +36,24 @@ def test_golden_fixtures(name):
     assert_same(ix.query(b, o, g["G"]), g["exp"]["p"], name + " again")
 
 
+def test_image_cache_gives_identical_results(tmp_path, monkeypatch):
+    """An index loaded from the CAMMIQ_IMAGE_CACHE file classifies exactly like a decoded one."""
+    import shutil
+    g = golden("f_deep")
+    pu, pd = str(tmp_path / "index_u.bin1"), str(tmp_path / "index_d.bin2")
+    for src, dst in ((g["pu"], pu), (g["pd"], pd)):
+        shutil.copy(src, dst)
+        shutil.copy(src + ".aux", dst + ".aux")
+    b, o = synth.concat_reads(g["reads"])
+    monkeypatch.setenv("CAMMIQ_IMAGE_CACHE", "1")
+    for expect_cached in (0, 1):
+        ix = cq.Index(pu, pd, device=0)
+        assert ix.info.reserved_ == expect_cached
+        assert_same(ix.query(b, o, g["G"]), g["exp"]["p"], f"cached={expect_cached}")
+        sc = ix.query(b, o, g["G"], mode=cq.MODE_SC)
+        assert sorted([a, b_, c] for (a, b_), c in sc["pairs"].items()) == g["exp"]["sc"]["pairs"]
+
+
 def test_survey_fixtures():
     """Indices written by the reference's build; numbers as recorded in SURVEY.md 8(c)."""
     g = golden("survey_F1")

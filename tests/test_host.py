@@ -237,3 +237,64 @@ def test_loader_survives_corrupted_files(tmp_path):
             assert e.code in (-2, -3, -4, -9), e
         open(victim, "wb").write(good[victim])
     assert failed > 20 and loaded + failed == 120
+
+
+def _snapshot(ix, probes):
+    d = ix.info_dict()
+    d.pop("device_bytes", None)
+    lv = [ix.leaves(t).tobytes() for t in (0, 1)]
+    return d, lv, [ix.probe(int(k)) for k in probes]
+
+
+@pytest.mark.parametrize("name", ["f_deep", "survey_F1"])
+def test_image_cache_roundtrip_and_invalidation(name, tmp_path, monkeypatch):
+    """CAMMIQ_IMAGE_CACHE=1: a cached load is indistinguishable from a decode,
+    and the cache is ignored + rewritten when a source file or the cache itself changes."""
+    import shutil
+    g = golden(name)
+    pu = str(tmp_path / "index_u.bin1")
+    pd = str(tmp_path / "index_d.bin2") if g["pd"] else None
+    for src, dst in ((g["pu"], pu), (g["pd"], pd)):
+        if src:
+            shutil.copy(src, dst)
+            shutil.copy(src + ".aux", dst + ".aux")
+    cache = pu + ".cqimg"
+    rng = np.random.default_rng(5)
+    base = cq.Index(pu, pd, device=-1)
+    h = base.hash_len
+    keys = [int(k) for k in rng.integers(0, 1 << (2 * h), 2000)]
+    # plus keys known to be present
+    tab = pyref.decode_index(pu)[2]
+    keys += [int("".join("{:02b}".format(synth.SYM[c]) for c in key[:h]), 2) for key, *_ in tab[:500]]
+    want = _snapshot(base, keys)
+    assert base.info.reserved_ == 0 and not os.path.exists(cache)      # opt-in: nothing written by default
+
+    monkeypatch.setenv("CAMMIQ_IMAGE_CACHE", "1")
+    first = cq.Index(pu, pd, device=-1)
+    assert first.info.reserved_ == 0 and os.path.exists(cache)
+    assert _snapshot(first, keys) == want
+    second = cq.Index(pu, pd, device=-1)
+    assert second.info.reserved_ == 1
+    assert _snapshot(second, keys) == want
+
+    # damaged cache -> silently rebuilt
+    raw = bytearray(open(cache, "rb").read())
+    open(cache, "wb").write(raw[:len(raw) - 7])
+    third = cq.Index(pu, pd, device=-1)
+    assert third.info.reserved_ == 0 and _snapshot(third, keys) == want
+    assert os.path.getsize(cache) == len(raw)
+    raw2 = bytearray(open(cache, "rb").read())
+    raw2[-3] ^= 0x40
+    open(cache, "wb").write(raw2)
+    assert cq.Index(pu, pd, device=-1).info.reserved_ == 0
+    assert cq.Index(pu, pd, device=-1).info.reserved_ == 1
+
+    # source touched -> stale cache ignored
+    st = os.stat(pu)
+    os.utime(pu, ns=(st.st_atime_ns, st.st_mtime_ns + 1_000_000_000))
+    fourth = cq.Index(pu, pd, device=-1)
+    assert fourth.info.reserved_ == 0 and _snapshot(fourth, keys) == want
+    assert cq.Index(pu, pd, device=-1).info.reserved_ == 1
+    # opting out again never reads it
+    monkeypatch.delenv("CAMMIQ_IMAGE_CACHE")
+    assert cq.Index(pu, pd, device=-1).info.reserved_ == 0
