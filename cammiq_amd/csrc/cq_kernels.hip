@@ -31,6 +31,7 @@
 // Integer only; MFMA is deliberately unused.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "cq_device.h"
 #include "cq_kernels.h"
@@ -52,6 +53,14 @@ constexpr int kWaves = kBlock / 64;
 #ifndef CQ_WORK_DRAIN
 #define CQ_WORK_DRAIN 64
 #endif
+#ifndef CQ_WIN_PER_LANE
+#define CQ_WIN_PER_LANE 4  /* consecutive windows one lane probes per pass */
+#endif
+constexpr uint32_t kWinPerLane = CQ_WIN_PER_LANE;
+#ifndef CQ_PRE_POS
+#define CQ_PRE_POS 8       /* adjacent m-mer positions one lane hashes in the pre-pass (<= 16) */
+#endif
+constexpr uint32_t kPrePos = CQ_PRE_POS;
 constexpr int kWorkDrain = CQ_WORK_DRAIN;     // drain a wave's list once it holds this many items
 constexpr int kWorkCap = kWorkDrain + 64;     // an iteration appends at most one item per lane
 
@@ -152,12 +161,19 @@ __device__ __forceinline__ uint32_t div_small(uint32_t idx, uint32_t d, uint32_t
     return __umul24(idx, magic) >> 19;
 }
 
-// The 64 bits of a staged row that start at base `off` (rows carry two zero pad words).
-__device__ __forceinline__ uint64_t row_bits64(const uint32_t *row, uint32_t off)
+// The 64 bits (32 bases) of a staged row that start at base `off`: two funnel shifts over three
+// words.  `off` may be negative or run past the read: a row is surrounded by other LDS words of
+// the same wave (rows carry two zero pad words), and callers never USE bases outside the read.
+__device__ __forceinline__ uint64_t row_bits64(const uint32_t *row, int off)
 {
-    const uint32_t q = off >> 4, s = (off & 15u) * 2u;
-    const uint64_t x = ((uint64_t)row[q] << 32) | row[q + 1];
-    return (x << s) | (((uint64_t)row[q + 2] << s) >> 32);
+    const int q = off >> 4;
+    const uint32_t s = ((uint32_t)off & 15u) * 2u;
+    const uint32_t w0 = row[q], w1 = row[q + 1], w2 = row[q + 2];
+    // v_alignbit takes a right-shift count in [0,31]; "left by 0" is the one case it cannot express
+    const uint32_t n = (32u - s) & 31u;
+    const uint32_t hi = s ? __builtin_amdgcn_alignbit(w0, w1, n) : w0;
+    const uint32_t lo = s ? __builtin_amdgcn_alignbit(w1, w2, n) : w1;
+    return ((uint64_t)hi << 32) | lo;
 }
 
 // hashtrie.cpp:350-369 on the path-compressed array trie.  `code` is the bucket root; returns
@@ -180,8 +196,8 @@ __device__ __forceinline__ uint32_t walk_trie(const DevIndex &ix, const uint32_t
             const uint32_t L = n.x & 63u;
             if (rem - j < L) return 0xFFFFFFFFu;                // the read ends inside the chain
             uint64_t syms;
-            if (!strand) syms = row_bits64(row, p + h + j) >> (64u - 2u * L);
-            else syms = (~rev2(row_bits64(row, p - j - L) >> (64u - 2u * L))) >> (64u - 2u * L);
+            if (!strand) syms = row_bits64(row, (int)(p + h + j)) >> (64u - 2u * L);
+            else syms = (~rev2(row_bits64(row, (int)(p - j - L)) >> (64u - 2u * L))) >> (64u - 2u * L);
             const uint64_t label = (((uint64_t)n.y << 32) | n.z) >> (64u - 2u * L);
             if (syms != label) return 0xFFFFFFFFu;              // some children[index] == NULL
             j += L;
@@ -373,8 +389,12 @@ __device__ __forceinline__ void decide(const QueryArgs &a, const Tile &t, uint32
 // R reads per wave sub-tile, CAP hit slots per read.  SLOW = exact path for reads whose hit
 // list overflowed CAP in the fast kernel: reads come from a device-side list, one per wave,
 // CAP covers the worst case (2 strands x 2 tables x 251 windows).
+#ifndef CQ_WAVES_PER_EU
+#define CQ_WAVES_PER_EU 6   /* register budget: 512 / 6 -> 80 VGPRs */
+#endif
 template <int R, int CAP, bool SLOW>
-__global__ void __launch_bounds__(kBlock) classify_kernel(DevIndex ix, QueryArgs a)
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(CQ_WAVES_PER_EU, CQ_WAVES_PER_EU)))
+classify_kernel(DevIndex ix, QueryArgs a)
 {
     static_assert(SLOW || R * 4 <= 64, "a sub-tile's rows must fit one 16-byte load per lane");
     extern __shared__ __align__(16) uint32_t smem[];
@@ -453,85 +473,128 @@ __global__ void __launch_bounds__(kBlock) classify_kernel(DevIndex ix, QueryArgs
         CQ_STAMP(0);   // staging
 
         // ---- pre-pass: hash the canonical m-mer at every base position, once.  A lane takes
-        // two adjacent positions: they share the index arithmetic and the row words.
+        // eight adjacent positions: their m-mers are bit-fields of one 64-bit piece of the row,
+        // their reverse complements bit-fields of that piece's reverse complement.
         {
-            const uint32_t ppr = (pmax + 1u) >> 1;                 // position pairs per read
-            const uint32_t total = nr * ppr;
+            const uint32_t gpr = (pmax + kPrePos - 1u) / kPrePos;  // position groups per read
+            const uint32_t total = nr * gpr;
+            const uint32_t mmask = m >= 16 ? 0xFFFFFFFFu : (1u << (2u * m)) - 1u;
             for (uint32_t it = lane; it < total; it += 64) {
-                const uint32_t rl = div_small(it, ppr, a.magic_pp), j = (it - __umul24(rl, ppr)) * 2u;
+                const uint32_t rl = div_small(it, gpr, a.magic_pp), j = (it - __umul24(rl, gpr)) * kPrePos;
                 const uint32_t len = t.len[rl];
-                if (j + m <= len) {
-                    const uint32_t *row = t.rows + __umul24(rl, swp);
-                    const uint64_t w64 = row_bits64(row, j);       // 32 bases starting at base j
-                    uint32_t *dst = t.phi + __umul24(rl, pmax) + j;
-                    dst[0] = cq_mmer_phi((uint32_t)(w64 >> (64u - 2u * m)), m);
-                    if (j + 1u + m <= len) dst[1] = cq_mmer_phi((uint32_t)((w64 << 2) >> (64u - 2u * m)), m);
+                if (j + m > len) continue;
+                const uint32_t *row = t.rows + __umul24(rl, swp);
+                const uint64_t w64 = row_bits64(row, (int)j);      // 32 bases starting at base j
+                const uint64_t rc64 = ~rev2(w64);
+                const uint32_t nv = len - m - j;                   // positions j .. j + min(nv, kPrePos-1) are valid
+                uint32_t *dst = t.phi + __umul24(rl, pmax) + j;
+#pragma unroll
+                for (uint32_t k = 0; k < kPrePos; k++) {
+                    const uint32_t f = (uint32_t)((w64 << (2u * k)) >> (64u - 2u * m));
+                    const uint32_t r = (uint32_t)(rc64 >> (2u * k)) & mmask;
+                    if (k <= nv) dst[k] = cq_phi32(f < r ? f : r);
                 }
             }
         }
         wave_sync();
         CQ_STAMP(1);   // pre-pass
 
-        // ---- probe phase: lane = (read, window).  The hot loop only DETECTS: it reads the
-        // window's bucket and compares the low 32 key bits of the four slots with the low
-        // words of the forward and the reverse-complement h-mer.  Nearly every window stops
-        // here.  A window with a low-word match (a hit, up to a 2^-32 fluke) or with an
-        // overflowed bucket is appended to the wave's work list -- ballot + prefix popcount,
-        // the list length is wave-uniform and lives in a register -- and gets the exact
-        // treatment (lookup_window) once 64 of them are waiting.
-        const uint32_t total = nr * wmax;
-        const uint32_t lo_shift = h < 16 ? 32u - 2u * h : 0u;   // keys shorter than 32 bits
+        // ---- probe phase: lane = (read, group of KW consecutive windows).  The hot loop only
+        // DETECTS: it reads a window's bucket and compares the low 32 key bits of the four slots
+        // with the low words of the forward and the reverse-complement h-mer.  Nearly every
+        // window stops here.  The windows of a lane share almost everything: their minima come
+        // out of one pass over h-m+KW hash words, neighbouring windows usually have the SAME
+        // minimizer, hence the same bucket (loaded once), and their low words are bit-fields of
+        // two 64-bit pieces of the row.  A window with a low-word match (a hit, up to a 2^-32
+        // fluke) or with an overflowed bucket is appended to the wave's work list -- ballot +
+        // prefix popcount, the list length is wave-uniform and lives in a register -- and gets
+        // the exact treatment (lookup_window) once 64 of them are waiting.
+        constexpr uint32_t KW = kWinPerLane;
+        const uint32_t gpr = (wmax + KW - 1u) / KW;             // window groups per read
+        const uint32_t total = nr * gpr;
+        const uint32_t hmask = h < 16 ? (0xFFFFFFFFu >> (32u - 2u * h)) : 0xFFFFFFFFu;   // keys shorter than 32 bits
         uint32_t nw = 0;
         for (uint32_t base = 0; base < total; base += 64) {
             const uint32_t idx = base + lane;
             bool act = idx < total;
-            uint32_t rl = 0, pw = 0, b = 0;
-            bool flag = false;
+            uint32_t rl = 0, pw0 = 0, len = 0, fl = 0;
+            uint32_t bk[KW];
+#pragma unroll
+            for (uint32_t k = 0; k < KW; k++) bk[k] = 0;
             if (act) {
-                rl = div_small(idx, wmax, a.magic_w);
-                pw = idx - __umul24(rl, wmax);
-                const uint32_t len = t.len[rl];
-                act = (len >= h) && (pw + h <= len);
+                rl = div_small(idx, gpr, a.magic_w);
+                pw0 = (idx - __umul24(rl, gpr)) * KW;
+                len = t.len[rl];
+                act = (len >= h) && (pw0 + h <= len);
             }
             if (act) {
-                // minimizer hash = min over the h-m+1 m-mers of the window
-                const uint32_t *ph = t.phi + __umul24(rl, pmax) + pw;
-                uint32_t mp;
-                if (nphi == 11) {        // h = 26 (CAMMiQ's default): all eleven LDS reads in flight at once
-                    const uint32_t v0 = ph[0], v1 = ph[1], v2 = ph[2], v3 = ph[3], v4 = ph[4], v5 = ph[5],
-                                   v6 = ph[6], v7 = ph[7], v8 = ph[8], v9 = ph[9], v10 = ph[10];
-                    mp = min(min(min(v0, v1), min(v2, v3)), min(min(min(v4, v5), min(v6, v7)), min(min(v8, v9), v10)));
+                const uint32_t nwin = len - h + 1u - pw0;         // valid windows from pw0 on (>= 1)
+                // minimizer hash of every window = min over its h-m+1 m-mers
+                const uint32_t *ph = t.phi + __umul24(rl, pmax) + pw0;
+                uint32_t mp[KW];
+                if (nphi == 11 && KW == 4) {   // h = 26 (CAMMiQ's default): fourteen LDS reads serve four windows
+                    const uint32_t v0 = ph[0], v1 = ph[1], v2 = ph[2], v3 = ph[3], v4 = ph[4], v5 = ph[5], v6 = ph[6],
+                                   v7 = ph[7], v8 = ph[8], v9 = ph[9], v10 = ph[10], v11 = ph[11], v12 = ph[12], v13 = ph[13];
+                    const uint32_t core = min(min(min(v3, v4), min(v5, v6)), min(min(v7, v8), min(v9, v10)));
+                    const uint32_t x = min(v1, v2), y = min(v11, v12);
+                    mp[0] = min(min(core, v0), x);
+                    mp[1 % KW] = min(min(core, x), v11);
+                    mp[2 % KW] = min(min(core, v2), y);
+                    mp[3 % KW] = min(min(core, y), v13);
                 } else {
-                    mp = ph[0];
-                    for (uint32_t i = 1; i < nphi; i++) mp = min(mp, ph[i]);
+#pragma unroll
+                    for (uint32_t k = 0; k < KW; k++) {
+                        uint32_t v = ph[k];
+                        for (uint32_t i = 1; i < nphi; i++) v = min(v, ph[k + i]);
+                        mp[k] = v;
+                    }
                 }
-                b = cq_bucket_of_minimizer(mp, ix.n_buckets);
-                const uint4 kl = ix.slots[(size_t)b * 4];      // key_lo[4]: the only bucket read of the hot loop
-                // low word of the forward h-mer: the 32 bits that END at the window's end;
-                // low word of the reverse complement: ~reverse of the 32 bits that START it
+                // buckets: key_lo[4] is the only bucket read of the hot loop; a window whose
+                // minimizer equals its left neighbour's reuses that neighbour's registers
+                uint4 kl[KW];
+                bk[0] = cq_bucket_of_minimizer(mp[0], ix.n_buckets);
+                kl[0] = ix.slots[(size_t)bk[0] * 4];
+#pragma unroll
+                for (uint32_t k = 1; k < KW; k++) {
+                    bk[k] = cq_bucket_of_minimizer(mp[k], ix.n_buckets);
+                    kl[k] = kl[k - 1];
+                    if (k < nwin && mp[k] != mp[k - 1]) kl[k] = ix.slots[(size_t)bk[k] * 4];
+                }
+                // low words.  Forward h-mer: the 32 bits that END at the window's end -- all KW of them
+                // inside the 64 bits that end at the last window's end.  Reverse complement: ~reverse of
+                // the 32 bits that START the window -- bit-fields of the reverse complement of the 64
+                // bits that start at the first window (reversal puts a window's first base into the
+                // lowest symbol, so the low 2h bits are the whole key when h < 16).
                 const uint32_t *row = t.rows + __umul24(rl, swp);
-                const uint32_t e = pw + h;                       // one past the last base
-                const uint32_t qe = e >> 4, se = (e & 15u) * 2u; // bit offset of the end in word qe
-                const uint32_t tail = qe ? (se ? __funnelshift_l(row[qe], row[qe - 1], se) : row[qe - 1])
-                                         : (row[0] >> (32u - se));
-                const uint32_t q = pw >> 4, s0 = (pw & 15u) * 2u;
-                const uint32_t head = s0 ? __funnelshift_l(row[q + 1], row[q], s0) : row[q];
-                const uint32_t hmask = lo_shift ? (0xFFFFFFFFu >> lo_shift) : 0xFFFFFFFFu;
-                const uint32_t flo = tail & hmask;
-                uint32_t y = __brev(head);
-                y = ((y >> 1) & 0x55555555u) | ((y & 0x55555555u) << 1);
-                // reversal puts the window's first base into the lowest symbol, so the low
-                // 2h bits are exactly the (whole, when h < 16) reverse complement
-                const uint32_t rlo = (~y) & hmask;
-                // slot 0's bit 0 is the overflow flag: compare it without that bit
-                flag = ((kl.x ^ flo) < 2u) | (kl.y == flo) | (kl.z == flo) | (kl.w == flo) |
-                       ((kl.x ^ rlo) < 2u) | (kl.y == rlo) | (kl.z == rlo) | (kl.w == rlo) | ((kl.x & 1u) != 0);
+                const uint64_t t64 = row_bits64(row, (int)(pw0 + (KW - 1u) + h) - 32);
+                const uint64_t rh64 = ~rev2(row_bits64(row, (int)pw0));
+#pragma unroll
+                for (uint32_t k = 0; k < KW; k++) {
+                    const uint32_t flo = (uint32_t)(t64 >> (2u * (KW - 1u - k))) & hmask;
+                    const uint32_t rlo = (uint32_t)(rh64 >> (2u * k)) & hmask;
+                    // slot 0's bit 0 is the overflow flag: compare it without that bit
+                    const bool f = ((kl[k].x ^ flo) < 2u) | (kl[k].y == flo) | (kl[k].z == flo) | (kl[k].w == flo) |
+                                   ((kl[k].x ^ rlo) < 2u) | (kl[k].y == rlo) | (kl[k].z == rlo) | (kl[k].w == rlo) |
+                                   ((kl[k].x & 1u) != 0);
+                    if (f && k < nwin) fl |= 1u << k;
+                }
             }
-            const uint64_t mask = __ballot(flag);
-            if (mask) {
-                const uint32_t off = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
-                                                               __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
-                if (flag) t.work[nw + off] = make_uint2(b, rl | (pw << 8));
+            // the one place where windows enter the work list (and where it is drained): a lane hands
+            // over one flagged window per trip -- most passes see one trip or none
+            for (;;) {
+                const bool has = fl != 0;
+                const uint64_t mask = __ballot(has);
+                if (!mask) break;
+                if (has) {
+                    const uint32_t k = (uint32_t)__ffs(fl) - 1u;
+                    fl &= fl - 1u;
+                    uint32_t b = bk[0];
+#pragma unroll
+                    for (uint32_t j = 1; j < KW; j++) b = (k == j) ? bk[j] : b;
+                    const uint32_t off = nw + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
+                                                                        __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
+                    t.work[off] = make_uint2(b, rl | ((pw0 + k) << 8));
+                }
                 nw += (uint32_t)__popcll(mask);
                 if (nw >= (uint32_t)kWorkDrain) { CQ_STAMP(2); drain_work<CAP>(ix, t, swp, nw); nw = 0; CQ_STAMP(3); }
             }
@@ -601,10 +664,10 @@ hipError_t launch_classify(const DevIndex &ix, QueryArgs a, int n_cus, hipStream
 {
     a.use_lds_hist = lds_hist_fits(a.n_genomes) ? 1 : 0;
     a.pmax = a.wmax + (ix.hash_len - ix.minimizer_len);   // m-mer positions: max_len - m + 1
-    a.magic_w = magic_of(a.wmax);
+    a.magic_w = magic_of((a.wmax + kWinPerLane - 1u) / kWinPerLane);
     a.magic_p = magic_of(a.pmax);
     a.magic_s = magic_of(a.stride_words);
-    a.magic_pp = magic_of((a.pmax + 1u) >> 1);
+    a.magic_pp = magic_of((a.pmax + kPrePos - 1u) / kPrePos);
     hipError_t e;
     // LDS above the 64 KiB default needs an explicit opt-in (large G)
     e = hipFuncSetAttribute((const void *)classify_kernel<kFastR, kFastCAP, false>,
@@ -616,8 +679,14 @@ hipError_t launch_classify(const DevIndex &ix, QueryArgs a, int n_cus, hipStream
     // fast kernel: persistent waves, each walking its own sub-tiles
     {
         const size_t sm = smem_bytes(kFastR, kFastCAP, a, a.use_lds_hist);
-        size_t per_cu = (160 * 1024) / (sm ? sm : 1);
-        if (per_cu > 6) per_cu = 6;   // measured: 7-8 workgroups per CU oversubscribe the L1 / TLB (-25 %)
+        // persistent grid = what is resident (registers and LDS decide), at most 6 workgroups per CU
+        // (measured: 7-8 oversubscribe the L1 / TLB, -25 %)
+        int per_cu = 0;
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)classify_kernel<kFastR, kFastCAP, false>,
+                                                         kBlock, sm);
+        if (e != hipSuccess) return e;
+        if (per_cu > 6) per_cu = 6;
+        if (const char *v = getenv("CAMMIQ_BLOCKS_PER_CU")) per_cu = atoi(v);   // tuning knob
         if (per_cu < 1) per_cu = 1;
         const uint64_t n_sub = (a.n_reads + kFastR - 1) / kFastR;
         uint64_t grid = (uint64_t)n_cus * per_cu;

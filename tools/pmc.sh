@@ -1,0 +1,24 @@
+#!/bin/bash
+# tools/pmc.sh TAG COUNTER...   one rocprofv3 --pmc pass of a short bench run; prints per-launch means
+# of the fast classify kernel.  (Counters only: never combined with sys/hip/hsa tracing.)
+set -euo pipefail
+root="$(cd "$(dirname "$0")/.." && pwd)"
+tag=$1; shift
+out=$root/gpurun_out/pmc_$tag
+rm -rf "$out"; mkdir -p "$out"
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --pmc "$@" --output-format csv -d "$out" -- python3 "$root/bench.py" --steps 2 --warmup 1 --no-cpu-baseline > "$out/bench.json" 2> "$out/err.log" || { tail -20 "$out/err.log"; exit 1; }
+python3 - "$out" <<'PY'
+import csv,glob,sys,collections
+out=sys.argv[1]
+acc=collections.defaultdict(list)
+for f in glob.glob(out+"/**/*counter_collection.csv",recursive=True):
+    for r in csv.DictReader(open(f)):
+        if "Lb0" in r["Kernel_Name"] or "false" in r["Kernel_Name"]:
+            acc[r["Counter_Name"]].append((r["Dispatch_Id"],float(r["Counter_Value"])))
+for k,v in sorted(acc.items()):
+    d=collections.defaultdict(float)
+    for i,x in v: d[i]+=x
+    vals=list(d.values())
+    print(f"{k:28s} launches {len(vals)}  mean/launch {sum(vals)/len(vals):.4g}")
+PY
