@@ -53,6 +53,9 @@ constexpr int kWaves = kBlock / 64;
 #ifndef CQ_WORK_DRAIN
 #define CQ_WORK_DRAIN 64
 #endif
+#ifndef CQ_MAX_BLOCKS_PER_CU
+#define CQ_MAX_BLOCKS_PER_CU 6
+#endif
 #ifndef CQ_WIN_PER_LANE
 #define CQ_WIN_PER_LANE 4  /* consecutive windows one lane probes per pass */
 #endif
@@ -644,7 +647,10 @@ classify_kernel(DevIndex ix, QueryArgs a)
 #ifndef CQ_FAST_R
 #define CQ_FAST_R 8
 #endif
-constexpr int kFastR = CQ_FAST_R, kFastCAP = 16;
+#ifndef CQ_FAST_CAP
+#define CQ_FAST_CAP 16
+#endif
+constexpr int kFastR = CQ_FAST_R, kFastCAP = CQ_FAST_CAP;
 constexpr int kSlowR = 1, kSlowCAP = 1024;
 
 static size_t smem_bytes(int R, int CAP, const QueryArgs &a, bool hist)
@@ -654,6 +660,7 @@ static size_t smem_bytes(int R, int CAP, const QueryArgs &a, bool hist)
 
 bool lds_hist_fits(uint32_t n_genomes)
 {
+    if (const char *v = getenv("CAMMIQ_LDS_HIST_MAX")) return 2 * ((size_t)n_genomes + 1) * 4 <= (size_t)atoi(v);   // tuning knob
     return 2 * ((size_t)n_genomes + 1) * 4 <= 32 * 1024;
 }
 
@@ -685,7 +692,7 @@ hipError_t launch_classify(const DevIndex &ix, QueryArgs a, int n_cus, hipStream
         e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)classify_kernel<kFastR, kFastCAP, false>,
                                                          kBlock, sm);
         if (e != hipSuccess) return e;
-        if (per_cu > 6) per_cu = 6;
+        if (per_cu > CQ_MAX_BLOCKS_PER_CU) per_cu = CQ_MAX_BLOCKS_PER_CU;
         if (const char *v = getenv("CAMMIQ_BLOCKS_PER_CU")) per_cu = atoi(v);   // tuning knob
         if (per_cu < 1) per_cu = 1;
         const uint64_t n_sub = (a.n_reads + kFastR - 1) / kFastR;
