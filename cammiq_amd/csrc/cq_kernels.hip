@@ -53,6 +53,9 @@ constexpr int kWaves = kBlock / 64;
 #ifndef CQ_WORK_DRAIN
 #define CQ_WORK_DRAIN 64
 #endif
+#ifndef CQ_EXP
+#define CQ_EXP 0   /* diagnostic builds only (wrong results): 1 no exact lookups, 2 no bucket chains, 3 no decision, 4 lookups stop after the first bucket, 5 no rcount atomics */
+#endif
 #ifndef CQ_MAX_BLOCKS_PER_CU
 #define CQ_MAX_BLOCKS_PER_CU 6
 #endif
@@ -285,7 +288,8 @@ __device__ __forceinline__ void lookup_window(const DevIndex &ix, const Tile &t,
     do {
         const Bucket bk = load_bucket(ix.slots, b++);
         more = match_bucket(bk, fw, rc, vf, vr, ff, fr);
-    } while (more);
+    } while (more && CQ_EXP != 2 && CQ_EXP != 4);
+    if (CQ_EXP == 4) return;
     if (vf.x | vf.y) resolve_pair<CAP>(ix, t, row, len, rl, vf, 0, pw);   // forward strand
     if (vr.x | vr.y) resolve_pair<CAP>(ix, t, row, len, rl, vr, 1, pw);   // reverse strand
 }
@@ -377,7 +381,7 @@ __device__ __forceinline__ void decide(const QueryArgs &a, const Tile &t, uint32
             } else atomicAdd(&t.scal[1], 1u);
         }
     }
-    if (counted && a.mode == CQ_MODE_P && a.rcount) {
+    if (counted && a.mode == CQ_MODE_P && a.rcount && CQ_EXP != 5) {
         for (uint32_t i = 0; i < n; i++) {
             const uint32_t g = gid[i];
             bool dup = false;
@@ -599,11 +603,11 @@ classify_kernel(DevIndex ix, QueryArgs a)
                     t.work[off] = make_uint2(b, rl | ((pw0 + k) << 8));
                 }
                 nw += (uint32_t)__popcll(mask);
-                if (nw >= (uint32_t)kWorkDrain) { CQ_STAMP(2); drain_work<CAP>(ix, t, swp, nw); nw = 0; CQ_STAMP(3); }
+                if (nw >= (uint32_t)kWorkDrain) { CQ_STAMP(2); if (CQ_EXP != 1) drain_work<CAP>(ix, t, swp, nw); nw = 0; CQ_STAMP(3); }
             }
         }
         CQ_STAMP(2);   // probe loop
-        if (nw) drain_work<CAP>(ix, t, swp, nw);
+        if (nw && CQ_EXP != 1) drain_work<CAP>(ix, t, swp, nw);
         CQ_STAMP(3);   // exact lookups
         wave_sync();
 
@@ -619,7 +623,7 @@ classify_kernel(DevIndex ix, QueryArgs a)
                         if (k < a.ovf_cap) a.ovf_list[k] = (uint32_t)(r0 + lane);
                         atomicAdd(&t.scal[3], 1u);
                     }
-                } else decide<CAP>(a, t, lane, n);
+                } else if (CQ_EXP != 3) decide<CAP>(a, t, lane, n);
             }
         }
         wave_sync();   // hit lists fully consumed before the next sub-tile resets them
