@@ -72,7 +72,8 @@ def test_survey_fixtures():
     assert_same(got, ref, "survey_F2")
 
 
-@pytest.mark.parametrize("h,k,lmax", [(5, 12, 20), (12, 12, 12), (16, 20, 40), (31, 31, 45)])
+@pytest.mark.parametrize("h,k,lmax", [(5, 12, 20), (12, 12, 12), (16, 20, 40), (17, 20, 30), (26, 26, 50),
+                                     (29, 30, 44), (31, 31, 45)])
 def test_random_indices_all_hash_lengths(tmp_path, h, k, lmax):
     gen = synth.clade_genomes(100 + h, 2, 3, 2000, 0.04)
     u, d = synth.select_markers(gen, k, lmax, keep_every=3, seed=h)
