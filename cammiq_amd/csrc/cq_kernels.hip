@@ -54,7 +54,7 @@ constexpr int kWaves = kBlock / 64;
 #define CQ_WORK_DRAIN 64
 #endif
 #ifndef CQ_EXP
-#define CQ_EXP 0   /* diagnostic builds only (wrong results): 1 no exact lookups, 2 no bucket chains, 3 no decision, 4 lookups stop after the first bucket, 5 no rcount atomics */
+#define CQ_EXP 0   /* diagnostic builds only (wrong results): 1 no exact lookups, 2 no bucket chains, 3 no decision, 4 lookups stop after the first bucket, 5 no rcount atomics, 6 hits resolved but not recorded */
 #endif
 #ifndef CQ_MAX_BLOCKS_PER_CU
 #define CQ_MAX_BLOCKS_PER_CU 6
@@ -232,7 +232,10 @@ __device__ __forceinline__ void wave_sync()
 template <int CAP>
 __device__ __forceinline__ void append_hit(const Tile &t, uint32_t rl, uint32_t gid, uint32_t r1, uint32_t r2)
 {
-    const uint32_t k = atomicAdd(&t.hitcnt[rl], 1u);
+    if (CQ_EXP == 6) { if (gid == 0xFFFFFFF0u) t.hitcnt[rl] = r1 + r2; return; }   // diagnostic: resolve, but record nothing
+    uint32_t k;
+    if (CQ_EXP == 7) { k = lane_id() & 7u; t.hitcnt[rl] = k + 1u; }   // diagnostic: no LDS atomic
+    else k = atomicAdd(&t.hitcnt[rl], 1u);
     if (k < (uint32_t)CAP) {
         t.hit_gid[rl * CAP + k] = gid;
         t.hit_r1[rl * CAP + k] = r1;
