@@ -9,17 +9,20 @@
 //     and staged in LDS (the "sliding window" lives there, not in registers of one thread);
 //     waves never synchronise with each other inside the main loop;
 //   * a pre-pass hashes every m-mer position of the tile once (canonical form, bijective
-//     32-bit hash) into LDS; a window's MINIMIZER is then the minimum over h-m+1 adjacent
-//     LDS words instead of h-m+1 hash evaluations per window;
-//   * every lane owns ONE window position of one read and handles BOTH strands of it:
-//     the forward h-mer is a bit-field of the row, the reverse-complement h-mer is
-//     ~bitreverse of it, so no reverse-complement read is ever materialised
-//     (reference: getRC + a second scan, query.cpp:447-450,503-527);
+//     32-bit hash) into LDS -- eight adjacent positions per lane, whose m-mers and reverse
+//     complements are bit-fields of one 64-bit piece of the row and of its reverse complement;
+//     a window's MINIMIZER is then the minimum over h-m+1 adjacent LDS words instead of
+//     h-m+1 hash evaluations per window;
+//   * every lane owns a GROUP of consecutive window positions of one read and handles BOTH
+//     strands of each: the forward h-mer is a bit-field of the row, the reverse-complement
+//     h-mer is ~bitreverse of it, so no reverse-complement read is ever materialised
+//     (reference: getRC + a second scan, query.cpp:447-450,503-527); the group's minima share
+//     one pass over the hash words and its low words two 64-bit pieces of the row;
 //   * the merged unique+doubly-unique table is addressed by the minimizer (cq_device.h):
 //     forward and reverse h-mer of a window share one 64-byte bucket, and so do runs of
-//     neighbouring windows = neighbouring lanes, whose identical loads the memory system
-//     serves with one HBM access (reference: four robin_hood lookups per window position,
-//     query.cpp:487-492,513-518);
+//     neighbouring windows -- inside a lane they reuse the loaded registers, across lanes the
+//     memory system serves identical loads with one HBM access (reference: four robin_hood
+//     lookups per window position, query.cpp:487-492,513-518);
 //   * the hot loop only DETECTS (low-word compare of the four slots); the few windows
 //     that may hit are compacted with ballot + prefix popcount into a per-wave LDS work
 //     list, which the wave drains with full lanes: exact 64-bit compare, bucket chain,
@@ -60,7 +63,7 @@ constexpr int kWaves = kBlock / 64;
 #define CQ_MAX_BLOCKS_PER_CU 6
 #endif
 #ifndef CQ_WIN_PER_LANE
-#define CQ_WIN_PER_LANE 4  /* consecutive windows one lane probes per pass */
+#define CQ_WIN_PER_LANE 5  /* consecutive windows one lane probes per pass: 100-bp reads, 8 per wave -> 120 lanes' worth = two passes */
 #endif
 constexpr uint32_t kWinPerLane = CQ_WIN_PER_LANE;
 #ifndef CQ_PRE_POS
@@ -551,6 +554,17 @@ classify_kernel(DevIndex ix, QueryArgs a)
                     mp[1 % KW] = min(min(core, x), v11);
                     mp[2 % KW] = min(min(core, v2), y);
                     mp[3 % KW] = min(min(core, y), v13);
+                } else if (nphi == 11 && KW == 5) {   // fifteen LDS reads serve five windows
+                    const uint32_t v0 = ph[0], v1 = ph[1], v2 = ph[2], v3 = ph[3], v4 = ph[4], v5 = ph[5], v6 = ph[6], v7 = ph[7],
+                                   v8 = ph[8], v9 = ph[9], v10 = ph[10], v11 = ph[11], v12 = ph[12], v13 = ph[13], v14 = ph[14];
+                    const uint32_t core = min(min(min(v4, v5), min(v6, v7)), min(min(v8, v9), v10));
+                    const uint32_t s3 = min(v3, core), s2 = min(v2, s3), s1 = min(v1, s2);
+                    const uint32_t p12 = min(v11, v12), p13 = min(p12, v13);
+                    mp[0] = min(v0, s1);
+                    mp[1 % KW] = min(s1, v11);
+                    mp[2 % KW] = min(s2, p12);
+                    mp[3 % KW] = min(s3, p13);
+                    mp[4 % KW] = min(core, min(p13, v14));
                 } else {
 #pragma unroll
                     for (uint32_t k = 0; k < KW; k++) {
