@@ -5,6 +5,8 @@
 // (query.cpp:458-1080): load + lay out + upload the index, then run the HIP classify
 // kernels on reads and hand the counters back.  No CPU classify path exists here.
 #include <hip/hip_runtime.h>
+#include <chrono>
+#include <memory>
 
 #include <cstdarg>
 #include <cstdio>
@@ -136,9 +138,15 @@ int upload(cq_index *ix)
     CQ_HIP(hipMemcpy(ix->d_slots, img.table.get(), sb, hipMemcpyHostToDevice));
     CQ_HIP(hipMemcpy(ix->d_nodes, img.nodes.data(), nb, hipMemcpyHostToDevice));
     {
-        std::vector<uint2> rr(nl);
-        for (size_t i = 0; i < nl; i++) rr[i] = make_uint2(img.leaf_r1[i], img.leaf_r2[i]);
-        if (nl) CQ_HIP(hipMemcpy(ix->d_leaf_rids, rr.data(), nl * sizeof(uint2), hipMemcpyHostToDevice));
+        std::unique_ptr<uint2[]> rr(new uint2[nl ? nl : 1]);
+        const unsigned nt = nl < (1u << 20) ? 1u : std::max(1u, std::min(std::thread::hardware_concurrency(), 16u));
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < nt; t++)
+            th.emplace_back([&, t] {
+                for (size_t i = nl * t / nt, e = nl * (t + 1) / nt; i < e; i++) rr[i] = make_uint2(img.leaf_r1[i], img.leaf_r2[i]);
+            });
+        for (auto &x : th) x.join();
+        if (nl) CQ_HIP(hipMemcpy(ix->d_leaf_rids, rr.get(), nl * sizeof(uint2), hipMemcpyHostToDevice));
     }
     CQ_HIP(hipMalloc((void **)&ix->d_ovf_count, sizeof(uint32_t)));
     CQ_HIP(hipMalloc((void **)&ix->d_stamps, 8 * sizeof(uint64_t)));
@@ -160,6 +168,18 @@ int upload(cq_index *ix)
 }
 
 }  // namespace
+
+// CAMMIQ_LOAD_TIMING=1: stage timings of cq_index_load on stderr (diagnostic)
+struct LoadTimer {
+    bool on = getenv("CAMMIQ_LOAD_TIMING") != nullptr;
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    void lap(const char *what)
+    {
+        const auto n = std::chrono::steady_clock::now();
+        if (on) fprintf(stderr, "[cq_index_load] %-22s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(n - t).count());
+        t = n;
+    }
+};
 
 extern "C" {
 
@@ -188,8 +208,11 @@ int cq_index_load(const char *path_u, const char *path_d, int device, cq_index *
     cq::SourceStamp stamp;
     const bool stamped = use_cache && cq::stamp_sources(path_u, have_d ? path_d : "", stamp);
     bool from_cache = false;
-    if (stamped && !getenv("CAMMIQ_KEYS_PER_BUCKET"))
-        from_cache = cq::load_image(cache_file, stamp, budget >= 1e29 ? ~0ull : (uint64_t)budget, ix->tab, ix->img);
+    LoadTimer lt;
+    const double kpb_override = getenv("CAMMIQ_KEYS_PER_BUCKET") ? atof(getenv("CAMMIQ_KEYS_PER_BUCKET")) : 0.0;
+    if (stamped)
+        from_cache = cq::load_image(cache_file, stamp, kpb_override, budget >= 1e29 ? ~0ull : (uint64_t)budget, ix->tab, ix->img);
+    if (from_cache) lt.lap("image cache read");
     // The reference loads the two files on two pthreads (query.cpp:112-116); same here.
     int rc_u = CQ_OK, rc_d = CQ_OK;
     std::string err_u, err_d;
@@ -201,6 +224,7 @@ int cq_index_load(const char *path_u, const char *path_d, int device, cq_index *
         if (rc_u != CQ_OK) { delete ix; return fail(rc_u, err_u); }
         if (rc_d != CQ_OK) { delete ix; return fail(rc_d, err_d); }
         if (!have_d) cq::make_empty_table(ix->tab[0].hash_len, ix->tab[1]);
+        lt.lap("decode");
         std::string err;
         // Average keys per 4-slot bucket of the device table.  Emptier tables overflow less
         // (fewer windows take the exact path): 1.0 costs 64 B of HBM per key (measured: 0.5 -> +2 %,
@@ -209,16 +233,17 @@ int cq_index_load(const char *path_u, const char *path_d, int device, cq_index *
         double kpb = 1.0;
         const double keys = (double)(ix->tab[0].bucket_key.size() + ix->tab[1].bucket_key.size());
         if (keys / kpb * 64.0 > budget) kpb = std::min(3.2, keys * 64.0 / budget);
-        if (const char *e = getenv("CAMMIQ_KEYS_PER_BUCKET")) kpb = atof(e);
+        if (kpb_override > 0.0) kpb = kpb_override;
         int rc = cq::build_image(ix->tab[0], ix->tab[1], kpb, ix->img, err);
         if (rc != CQ_OK) { delete ix; return fail(rc, err); }
+        lt.lap("layout");
         // bucket/node arrays of the decode stage are no longer needed; leaves are (cq_index_leaves)
         for (int t = 0; t < 2; t++) {
             std::vector<uint64_t>().swap(ix->tab[t].bucket_key);
             std::vector<uint32_t>().swap(ix->tab[t].bucket_code);
             std::vector<cq::Node>().swap(ix->tab[t].nodes);
         }
-        if (stamped && !getenv("CAMMIQ_KEYS_PER_BUCKET")) (void)cq::save_image(cache_file, stamp, ix->tab, ix->img);
+        if (stamped) { (void)cq::save_image(cache_file, stamp, kpb_override, ix->tab, ix->img); lt.lap("image cache write"); }
     } catch (const std::bad_alloc &) {
         delete ix;
         return fail(CQ_ERR_NOMEM, "out of memory while loading the index");
@@ -231,6 +256,7 @@ int cq_index_load(const char *path_u, const char *path_d, int device, cq_index *
     ix->device = device;
     if (device >= 0) {
         int rc = upload(ix);
+        lt.lap("upload");
         if (rc != CQ_OK) { release_device(ix); delete ix; return rc; }
         // the image now lives in HBM: drop the host copy (cq_index_probe needs a CQ_DEVICE_NONE handle)
         ix->n_trie_nodes = ix->img.nodes.size() - 1;

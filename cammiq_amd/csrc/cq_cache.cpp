@@ -13,6 +13,9 @@
 
 #include <cstdio>
 #include <cstring>
+#include <algorithm>
+#include <thread>
+#include <vector>
 
 #include "cq_index.hpp"
 
@@ -20,7 +23,7 @@ namespace cq {
 
 namespace {
 
-constexpr uint32_t kLayoutRev = 7;   // bump whenever cq_device.h's table / trie / minimizer layout changes
+constexpr uint32_t kLayoutRev = 9;   // bump whenever cq_device.h's table / trie / minimizer layout changes
 
 struct Header {
     char magic[8];              // "CQIMG\0\0\0"
@@ -29,6 +32,7 @@ struct Header {
     uint32_t hash_len, doubly[2], max_chain, max_refid, pad_;
     uint64_t n_file_buckets[2], n_leaves[2];
     uint64_t n_buckets, n_buckets_alloc, n_keys, n_overflowed, n_nodes, table_words;
+    double kpb_override;        // CAMMIQ_KEYS_PER_BUCKET the image was built with, 0 = automatic
     uint64_t payload_bytes, checksum;   // checksum over the header fields above + a sample of the payload
 };
 
@@ -65,14 +69,33 @@ bool write_all(int fd, const void *p, size_t n)
     return true;
 }
 
-bool read_all(int fd, void *p, size_t n)
+bool pread_all(int fd, void *p, size_t n, uint64_t off)
 {
     uint8_t *b = (uint8_t *)p;
     while (n) {
-        ssize_t r = ::read(fd, b, n > (1u << 30) ? (1u << 30) : n);
+        ssize_t r = ::pread(fd, b, n > (1u << 30) ? (1u << 30) : n, (off_t)off);
         if (r <= 0) return false;
-        b += r; n -= (size_t)r;
+        b += r; n -= (size_t)r; off += (uint64_t)r;
     }
+    return true;
+}
+
+// A multi-GB section comes out of the page cache at memcpy speed: use all cores (first touch of the
+// destination included).
+bool read_section(int fd, void *p, size_t n, uint64_t off)
+{
+    unsigned hw = std::thread::hardware_concurrency();
+    const unsigned nt = n < (64u << 20) ? 1u : std::max(1u, std::min(hw ? hw : 1u, 16u));
+    if (nt == 1) return pread_all(fd, p, n, off);
+    std::vector<std::thread> th;
+    std::vector<char> ok(nt, 0);
+    for (unsigned t = 0; t < nt; t++)
+        th.emplace_back([&, t] {
+            const size_t lo = (n / nt) * t, hi = t + 1 == nt ? n : (n / nt) * (t + 1);
+            ok[t] = pread_all(fd, (uint8_t *)p + lo, hi - lo, off + lo) ? 1 : 0;
+        });
+    for (auto &x : th) x.join();
+    for (unsigned t = 0; t < nt; t++) if (!ok[t]) return false;
     return true;
 }
 
@@ -92,7 +115,8 @@ bool stamp_sources(const std::string &path_u, const std::string &path_d, SourceS
     return true;
 }
 
-bool save_image(const std::string &file, const SourceStamp &src, const DecodedTable tab[2], const FlatImage &img)
+bool save_image(const std::string &file, const SourceStamp &src, double kpb_override, const DecodedTable tab[2],
+                const FlatImage &img)
 {
     Header h;
     memset(&h, 0, sizeof h);
@@ -100,6 +124,7 @@ bool save_image(const std::string &file, const SourceStamp &src, const DecodedTa
     h.layout_rev = kLayoutRev; h.slots_per_bucket = CQ_SLOTS_PER_BUCKET; h.bucket_words = CQ_BUCKET_WORDS;
     h.max_minimizer = CQ_MAX_MINIMIZER;
     h.src = src;
+    h.kpb_override = kpb_override;
     h.hash_len = img.hash_len; h.max_chain = img.max_chain; h.max_refid = img.max_refid;
     for (int t = 0; t < 2; t++) {
         h.doubly[t] = tab[t].doubly; h.n_file_buckets[t] = tab[t].n_file_buckets; h.n_leaves[t] = tab[t].leaves.size();
@@ -122,15 +147,15 @@ bool save_image(const std::string &file, const SourceStamp &src, const DecodedTa
     return ok;
 }
 
-bool load_image(const std::string &file, const SourceStamp &src, uint64_t max_table_bytes, DecodedTable tab[2],
-                FlatImage &img)
+bool load_image(const std::string &file, const SourceStamp &src, double kpb_override, uint64_t max_table_bytes,
+                DecodedTable tab[2], FlatImage &img)
 {
     int fd = ::open(file.c_str(), O_RDONLY);
     if (fd < 0) return false;
     Header h;
-    bool ok = read_all(fd, &h, sizeof h) && memcmp(h.magic, "CQIMG\0\0\0", 8) == 0 && h.layout_rev == kLayoutRev &&
+    bool ok = pread_all(fd, &h, sizeof h, 0) && memcmp(h.magic, "CQIMG\0\0\0", 8) == 0 && h.layout_rev == kLayoutRev &&
               h.slots_per_bucket == CQ_SLOTS_PER_BUCKET && h.bucket_words == CQ_BUCKET_WORDS &&
-              h.max_minimizer == CQ_MAX_MINIMIZER && memcmp(&h.src, &src, sizeof src) == 0 &&
+              h.max_minimizer == CQ_MAX_MINIMIZER && memcmp(&h.src, &src, sizeof src) == 0 && h.kpb_override == kpb_override &&
               h.table_words == h.n_buckets_alloc * CQ_BUCKET_WORDS && h.n_nodes >= 1 &&
               h.table_words * sizeof(uint32_t) <= max_table_bytes && h.hash_len >= 1 && h.hash_len <= 31;
     struct stat st;
@@ -153,7 +178,8 @@ bool load_image(const std::string &file, const SourceStamp &src, uint64_t max_ta
     }
     if (ok) {
         void *sec[4] = {tab[0].leaves.data(), tab[1].leaves.data(), img.table.get(), img.nodes.data()};
-        for (int i = 0; i < 4 && ok; i++) ok = read_all(fd, sec[i], len[i]);
+        uint64_t off = sizeof h;
+        for (int i = 0; i < 4 && ok; i++) { ok = read_section(fd, sec[i], len[i], off); off += len[i]; }
         if (ok) ok = sample_sum(h, (const void *const *)sec, len) == h.checksum;
     }
     ::close(fd);

@@ -63,9 +63,10 @@ int build_image(const DecodedTable &u, const DecodedTable &d, double keys_per_bu
 // Optional on-disk cache of the finished image (cq_cache.cpp).
 struct SourceStamp { uint64_t size[4]; int64_t mtime_ns[4]; };   // index_u, .aux, index_d, .aux (0 = absent)
 bool stamp_sources(const std::string &path_u, const std::string &path_d, SourceStamp &s);
-bool save_image(const std::string &file, const SourceStamp &src, const DecodedTable tab[2], const FlatImage &img);
-bool load_image(const std::string &file, const SourceStamp &src, uint64_t max_table_bytes, DecodedTable tab[2],
-                FlatImage &img);
+bool save_image(const std::string &file, const SourceStamp &src, double kpb_override, const DecodedTable tab[2],
+                const FlatImage &img);
+bool load_image(const std::string &file, const SourceStamp &src, double kpb_override, uint64_t max_table_bytes,
+                DecodedTable tab[2], FlatImage &img);
 
 // Host mirror of the device lookup (used by tests of the layout through the C ABI and by
 // build_image's self-check).  Returns the slot values for `key` (0,0 when absent).

@@ -23,7 +23,11 @@
 // table has CQ_SPILL_TAIL buckets past the hash range.
 #include <algorithm>
 #include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <thread>
 
 #include "cq_index.hpp"
@@ -39,42 +43,70 @@ struct Entry {
     uint32_t val_u, val_d;
 };
 
+// Order by (home bucket, key).  Equal keys (the same h-mer in both tables, or twice in one file)
+// end up adjacent in any order: the merge step looks at the whole group.
 inline bool entry_less(const Entry &a, const Entry &b)
 {
     if (a.home != b.home) return a.home < b.home;
-    if (a.key != b.key) return a.key < b.key;
-    return a.seq < b.seq;
+    return a.key < b.key;
 }
 
-// Sort by (home, key, seq).  Parallel: partition by the top bits of `home`, sort the parts.
-void sort_entries(std::vector<Entry> &e, uint32_t n_buckets)
+unsigned worker_count(size_t n_items)
 {
-    const size_t n = e.size();
+    if (const char *v = getenv("CAMMIQ_LAYOUT_THREADS")) return (unsigned)std::max(1, atoi(v));   // tests: 1 = serial
     unsigned hw = std::thread::hardware_concurrency();
-    unsigned nt = std::min(hw ? hw : 1u, 32u);
-    if (n < (1u << 18) || nt < 2) { std::sort(e.begin(), e.end(), entry_less); return; }
-    const unsigned parts = 256;
-    std::vector<size_t> cnt(parts + 1, 0);
-    auto part_of = [&](uint32_t home) { return (unsigned)(((uint64_t)home * parts) / n_buckets); };
-    for (size_t i = 0; i < n; i++) cnt[part_of(e[i].home) + 1]++;
-    for (unsigned p = 0; p < parts; p++) cnt[p + 1] += cnt[p];
-    std::vector<Entry> tmp(n);
-    {
-        std::vector<size_t> cur(cnt.begin(), cnt.end() - 1);
-        for (size_t i = 0; i < n; i++) tmp[cur[part_of(e[i].home)]++] = e[i];
-    }
-    e.swap(tmp);
+    return n_items < (1u << 16) ? 1u : std::max(1u, std::min(hw ? hw : 1u, 32u));
+}
+
+template <class F>
+void parallel_for(unsigned nt, F f)
+{
+    if (nt <= 1) { f(0u); return; }
     std::vector<std::thread> th;
-    std::atomic<unsigned> next{0};
-    for (unsigned t = 0; t < nt; t++)
-        th.emplace_back([&] {
-            for (;;) {
-                unsigned p = next.fetch_add(1);
-                if (p >= parts) break;
-                std::sort(e.begin() + cnt[p], e.begin() + cnt[p + 1], entry_less);
-            }
-        });
+    for (unsigned t = 0; t < nt; t++) th.emplace_back(f, t);
     for (auto &x : th) x.join();
+}
+
+// Sort by (home, key): partition by the top bits of `home` (parallel count + parallel scatter),
+// then sort the parts on all cores.  part_begin[p] .. part_begin[p+1] are the parts of the result.
+constexpr unsigned kParts = 256;
+
+// The result lives in a fresh uninitialised buffer (first touched by the scattering threads); `e` is released.
+std::unique_ptr<Entry[]> sort_entries(std::unique_ptr<Entry[]> &e, size_t n, uint32_t n_buckets, std::vector<size_t> &part_begin)
+{
+    const unsigned nt = worker_count(n);
+    auto part_of = [&](uint32_t home) { return (unsigned)(((uint64_t)home * kParts) / n_buckets); };
+    std::vector<size_t> cnt((size_t)nt * kParts, 0);
+    parallel_for(nt, [&](unsigned t) {
+        const size_t lo = n * t / nt, hi = n * (t + 1) / nt;
+        size_t *c = &cnt[(size_t)t * kParts];
+        for (size_t i = lo; i < hi; i++) c[part_of(e[i].home)]++;
+    });
+    // exclusive prefix over (part, thread): thread t's entries of part p go after threads < t's
+    part_begin.assign(kParts + 1, 0);
+    size_t run = 0;
+    for (unsigned p = 0; p < kParts; p++) {
+        part_begin[p] = run;
+        for (unsigned t = 0; t < nt; t++) { const size_t c = cnt[(size_t)t * kParts + p]; cnt[(size_t)t * kParts + p] = run; run += c; }
+    }
+    part_begin[kParts] = run;
+    std::unique_ptr<Entry[]> out(new Entry[n ? n : 1]);
+    Entry *tmp = out.get();
+    parallel_for(nt, [&](unsigned t) {
+        const size_t lo = n * t / nt, hi = n * (t + 1) / nt;
+        size_t *c = &cnt[(size_t)t * kParts];
+        for (size_t i = lo; i < hi; i++) tmp[c[part_of(e[i].home)]++] = e[i];
+    });
+    e.reset();
+    std::atomic<unsigned> next{0};
+    parallel_for(nt, [&](unsigned) {
+        for (;;) {
+            const unsigned p = next.fetch_add(1);
+            if (p >= kParts) break;
+            std::sort(tmp + part_begin[p], tmp + part_begin[p + 1], entry_less);
+        }
+    });
+    return out;
 }
 
 // Path compression of the array trie.  The reference walks one heap node per base
@@ -132,9 +164,23 @@ struct Compressor {
 
 }  // namespace
 
+namespace {
+struct StageTimer {   // CAMMIQ_LOAD_TIMING=1: stage timings on stderr (diagnostic)
+    bool on = getenv("CAMMIQ_LOAD_TIMING") != nullptr;
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    void lap(const char *what)
+    {
+        const auto n = std::chrono::steady_clock::now();
+        if (on) fprintf(stderr, "[build_image]   %-20s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(n - t).count());
+        t = n;
+    }
+};
+}  // namespace
+
 int build_image(const DecodedTable &u, const DecodedTable &d, double keys_per_bucket,
                 FlatImage &img, std::string &err)
 {
+    StageTimer st;
     img = FlatImage();
     if (u.hash_len != d.hash_len) { err = "hash lengths of the two index files differ"; return CQ_ERR_HASHLEN; }
     img.hash_len = u.hash_len;
@@ -168,15 +214,22 @@ int build_image(const DecodedTable &u, const DecodedTable &d, double keys_per_bu
     img.leaf_r1.resize(nu + nd);
     img.leaf_r2.resize(nu + nd);
     uint32_t maxr = 0;
-    for (uint64_t i = 0; i < nu; i++) {
-        img.leaf_r1[i] = u.leaves[i].refID1; img.leaf_r2[i] = u.leaves[i].refID2;
-        maxr = std::max(maxr, std::max(u.leaves[i].refID1, u.leaves[i].refID2));
-    }
-    for (uint64_t i = 0; i < nd; i++) {
-        img.leaf_r1[nu + i] = d.leaves[i].refID1; img.leaf_r2[nu + i] = d.leaves[i].refID2;
-        maxr = std::max(maxr, std::max(d.leaves[i].refID1, d.leaves[i].refID2));
+    {
+        const unsigned ntl = worker_count(nu + nd);
+        std::vector<uint32_t> mx(ntl, 0);
+        parallel_for(ntl, [&](unsigned t) {
+            uint32_t m = 0;
+            for (uint64_t i = (nu + nd) * t / ntl, e = (nu + nd) * (t + 1) / ntl; i < e; i++) {
+                const cq_leaf &lf = i < nu ? u.leaves[i] : d.leaves[i - nu];
+                img.leaf_r1[i] = lf.refID1; img.leaf_r2[i] = lf.refID2;
+                m = std::max(m, std::max(lf.refID1, lf.refID2));
+            }
+            mx[t] = m;
+        });
+        for (uint32_t m : mx) maxr = std::max(maxr, m);
     }
     img.max_refid = maxr;
+    st.lap("link + leaf refIDs");
 
     // ---- entries of both tables, sorted by (home bucket, key, file order)
     const uint64_t nb_u = u.bucket_key.size(), nb_d = d.bucket_key.size();
@@ -187,115 +240,167 @@ int build_image(const DecodedTable &u, const DecodedTable &d, double keys_per_bu
     img.n_buckets = nbk;
     const uint32_t n_buckets = (uint32_t)nbk;
 
-    std::vector<Entry> ent(nb_u + nb_d);
-    // trie codes first (path compression appends to one node array: sequential) ...
-    for (uint64_t i = 0; i < nb_u; i++)
-        ent[i] = Entry{0, (uint32_t)i, u.bucket_key[i], comp.run(u.bucket_code[i]), 0};
-    for (uint64_t i = 0; i < nb_d; i++)
-        ent[nb_u + i] = Entry{0, (uint32_t)i, d.bucket_key[i], 0, comp.run(relink_d(d.bucket_code[i]))};
+    std::unique_ptr<Entry[]> ent(new Entry[nb_u + nb_d ? nb_u + nb_d : 1]);   // uninitialised: filled (first touched) in parallel
+    const size_t n_ent = nb_u + nb_d;
+    // trie codes first: a bucket root that is a leaf (the usual case) is its own code; the others go
+    // through path compression, which appends to one node array and therefore runs serially, in file order
+    {
+        const unsigned nte = worker_count(nb_u + nb_d);
+        std::vector<std::vector<uint64_t>> deep(nte);
+        parallel_for(nte, [&](unsigned t) {
+            for (uint64_t i = (nb_u + nb_d) * t / nte, e = (nb_u + nb_d) * (t + 1) / nte; i < e; i++) {
+                if (i < nb_u) ent[i] = Entry{0, (uint32_t)i, u.bucket_key[i], u.bucket_code[i], 0};
+                else ent[i] = Entry{0, (uint32_t)(i - nb_u), d.bucket_key[i - nb_u], 0, relink_d(d.bucket_code[i - nb_u])};
+                const uint32_t code = ent[i].val_u | ent[i].val_d;
+                if (code && !(code & CQ_LEAF_BIT)) deep[t].push_back(i);
+            }
+        });
+        for (unsigned t = 0; t < nte; t++)
+            for (uint64_t i : deep[t]) {
+                if (i < nb_u) ent[i].val_u = comp.run(ent[i].val_u);
+                else ent[i].val_d = comp.run(ent[i].val_d);
+            }
+    }
+    st.lap("compress tries");
     // ... then the home buckets (a minimizer scan per key: the expensive part) on all cores
     {
-        unsigned hw = std::thread::hardware_concurrency();
-        const unsigned nt = ent.size() < (1u << 16) ? 1u : std::max(1u, std::min(hw ? hw : 1u, 32u));
+        const unsigned nt = worker_count(n_ent);
         const uint32_t hl = img.hash_len;
-        auto work = [&](unsigned t) {
-            const size_t lo = ent.size() * t / nt, hi = ent.size() * (t + 1) / nt;
+        parallel_for(nt, [&](unsigned t) {
+            const size_t lo = n_ent * t / nt, hi = n_ent * (t + 1) / nt;
             for (size_t i = lo; i < hi; i++) ent[i].home = cq_home_bucket(ent[i].key, hl, n_buckets);
-        };
-        if (nt == 1) work(0);
-        else {
-            std::vector<std::thread> th;
-            for (unsigned t = 0; t < nt; t++) th.emplace_back(work, t);
-            for (auto &x : th) x.join();
-        }
+        });
     }
     if (img.nodes.size() >= (1ull << 30)) { err = "more than 2^30 trie nodes after path compression"; return CQ_ERR_LIMIT; }
     std::vector<Node>().swap(linked);
-    sort_entries(ent, n_buckets);
+    st.lap("home buckets");
+    std::vector<size_t> part_begin;
+    const std::unique_ptr<Entry[]> sorted = sort_entries(ent, n_ent, n_buckets, part_begin);
+    Entry *const E = sorted.get();
+    st.lap("sort");
 
     // ---- merge duplicates (same key in both tables, or repeated within one file: the later
-    //      bucket wins, as map64[bucket] = root overwrites -- hashtrie.cpp:500)
-    size_t w = 0;
-    for (size_t i = 0; i < ent.size();) {
-        Entry m = ent[i];
-        size_t j = i + 1;
-        while (j < ent.size() && ent[j].key == m.key) j++;
-        // per table, the entry with the highest file position wins
-        uint32_t su = 0, sd = 0; bool hu = false, hd = false;
-        for (size_t k = i; k < j; k++) {
-            if (ent[k].val_u && (!hu || ent[k].seq >= su)) { m.val_u = ent[k].val_u; su = ent[k].seq; hu = true; }
-            if (ent[k].val_d && (!hd || ent[k].seq >= sd)) { m.val_d = ent[k].val_d; sd = ent[k].seq; hd = true; }
-        }
-        // a unique depth-0 leaf with a free val_d slot carries its refID inline (cq_device.h)
-        if ((m.val_u & CQ_LEAF_BIT) && m.val_d == 0) {
-            const uint32_t g = m.val_u & ~CQ_LEAF_BIT;
-            if (img.leaf_r2[g] == 0 && img.leaf_r1[g] < CQ_INLINE_RID_BIT) m.val_d = CQ_INLINE_RID_BIT | img.leaf_r1[g];
-        }
-        ent[w++] = m;
-        i = j;
+    //      bucket wins, as map64[bucket] = root overwrites -- hashtrie.cpp:500).  Equal keys share
+    //      their home bucket, hence their part: every part is compacted on its own.
+    const unsigned nt = worker_count(n_ent);
+    std::vector<size_t> part_end(kParts, 0);
+    {
+        std::atomic<unsigned> nextp{0};
+        parallel_for(nt, [&](unsigned) {
+            for (;;) {
+                const unsigned p = nextp.fetch_add(1);
+                if (p >= kParts) break;
+                size_t w = part_begin[p];
+                const size_t hi = part_begin[p + 1];
+                for (size_t i = part_begin[p]; i < hi;) {
+                    Entry m = E[i];
+                    size_t j = i + 1;
+                    while (j < hi && E[j].key == m.key) j++;
+                    // per table, the entry with the highest file position wins
+                    uint32_t su = 0, sd = 0; bool hu = false, hd = false;
+                    for (size_t k = i; k < j; k++) {
+                        if (E[k].val_u && (!hu || E[k].seq >= su)) { m.val_u = E[k].val_u; su = E[k].seq; hu = true; }
+                        if (E[k].val_d && (!hd || E[k].seq >= sd)) { m.val_d = E[k].val_d; sd = E[k].seq; hd = true; }
+                    }
+                    // a unique depth-0 leaf with a free val_d slot carries its refID inline (cq_device.h)
+                    if ((m.val_u & CQ_LEAF_BIT) && m.val_d == 0) {
+                        const uint32_t g = m.val_u & ~CQ_LEAF_BIT;
+                        if (img.leaf_r2[g] == 0 && img.leaf_r1[g] < CQ_INLINE_RID_BIT) m.val_d = CQ_INLINE_RID_BIT | img.leaf_r1[g];
+                    }
+                    E[w++] = m;
+                    i = j;
+                }
+                part_end[p] = w;
+            }
+        });
     }
-    ent.resize(w);
-    img.n_keys = w;
+    img.n_keys = 0;
+    for (unsigned p = 0; p < kParts; p++) img.n_keys += part_end[p] - part_begin[p];
+    st.lap("merge duplicates");
 
-    // ---- linear sweep placement
+    // ---- placement: a linear sweep over the buckets.  Keys sorted by home bucket are dealt into
+    //      buckets in order; what does not fit is carried to the next bucket, whose predecessor
+    //      gets the overflow bit.  Part p owns the buckets its keys are homed in, so all parts
+    //      sweep at once (each starting with an empty carry and writing every one of its buckets
+    //      exactly once: no separate initialisation pass); what a part could not place inside its
+    //      own range is then carried, in order, into the next part, whose first buckets are
+    //      redone until the carry has drained -- from there on the independent sweep was right.
     img.n_buckets_alloc = nbk + CQ_SPILL_TAIL;
     img.table_words = img.n_buckets_alloc * CQ_BUCKET_WORDS;
-    img.table.reset(new uint32_t[img.table_words]);   // uninitialised: the threads below first-touch it
-    {
-        unsigned hw = std::thread::hardware_concurrency();
-        const unsigned nt = img.n_buckets_alloc < (1u << 16) ? 1u : std::max(1u, std::min(hw ? hw : 1u, 32u));
-        auto init = [&](unsigned t) {
-            const uint64_t lo = img.n_buckets_alloc * t / nt, hi = img.n_buckets_alloc * (t + 1) / nt;
-            for (uint64_t b = lo; b < hi; b++) {
-                uint32_t *bw = &img.table[b * CQ_BUCKET_WORDS];
-                for (int k = 0; k < CQ_SLOTS_PER_BUCKET; k++) {
-                    bw[CQ_BW_KEY_LO + k] = bw[CQ_BW_KEY_HI + k] = 0xFFFFFFFFu;
-                    bw[CQ_BW_VAL_U + k] = bw[CQ_BW_VAL_D + k] = 0u;
+    img.table.reset(new uint32_t[img.table_words]);   // uninitialised: the sweeps below first-touch it
+    auto first_bucket = [&](unsigned p) -> uint64_t {   // smallest home with part_of(home) == p
+        return p >= kParts ? img.n_buckets_alloc : ((uint64_t)p * nbk + kParts - 1) / kParts;
+    };
+    struct SweepOut { std::vector<Entry> left; uint64_t overflowed = 0; uint32_t max_chain = 1; uint64_t stopped_at = 0; };
+    // Fill buckets [b0, b1) of part p from its keys, `carry` first.  until_drained: stop after the first
+    // bucket that leaves nothing waiting (and report where); fix: subtract the flags the redone buckets had.
+    auto sweep = [&](unsigned p, uint64_t b0, uint64_t b1, const std::vector<Entry> &carry, bool until_drained, SweepOut &o) {
+        size_t qpos = 0, cl = part_begin[p], nx = part_begin[p];
+        const size_t hi = part_end[p];
+        o.stopped_at = b1;
+        for (uint64_t b = b0; b < b1; b++) {
+            while (nx < hi && E[nx].home <= b) nx++;
+            uint32_t *bw = &img.table[b * CQ_BUCKET_WORDS];
+            if (until_drained && (bw[CQ_BW_KEY_LO] & 1u) && bw[CQ_BW_KEY_HI] != 0xFFFFFFFFu) o.overflowed--;   // flag of the sweep being redone
+            for (int k = 0; k < CQ_SLOTS_PER_BUCKET; k++) {
+                bw[CQ_BW_KEY_LO + k] = bw[CQ_BW_KEY_HI + k] = 0xFFFFFFFFu;
+                bw[CQ_BW_VAL_U + k] = bw[CQ_BW_VAL_D + k] = 0u;
+            }
+            bw[CQ_BW_KEY_LO] = 0xFFFFFFFEu;   // empty slot 0: overflow flag (bit 0) must read 0
+            const size_t avail = (carry.size() - qpos) + (nx - cl);
+            const size_t take = std::min<size_t>(avail, CQ_SLOTS_PER_BUCKET);
+            for (size_t k = 0; k < take; k++) {
+                const Entry &e = qpos < carry.size() ? carry[qpos++] : E[cl++];
+                uint32_t lo = (uint32_t)e.key, hi32 = (uint32_t)(e.key >> 32);
+                if (k == 0) {   // slot 0 lends bit 0 of key_lo to the overflow flag
+                    if (lo & 1u) hi32 |= CQ_SLOT0_BIT0_IN_HI;
+                    lo &= ~1u;
                 }
-                bw[CQ_BW_KEY_LO] = 0xFFFFFFFEu;   // empty slot 0: overflow flag (bit 0) must read 0
+                bw[CQ_BW_KEY_LO + k] = lo;
+                bw[CQ_BW_KEY_HI + k] = hi32;
+                bw[CQ_BW_VAL_U + k] = e.val_u;
+                bw[CQ_BW_VAL_D + k] = e.val_d;
+                const uint32_t chain = (uint32_t)(b - e.home) + 1;
+                if (chain > o.max_chain) o.max_chain = chain;
             }
-        };
-        if (nt == 1) init(0);
-        else {
-            std::vector<std::thread> th;
-            for (unsigned t = 0; t < nt; t++) th.emplace_back(init, t);
-            for (auto &x : th) x.join();
+            if (avail > take) {   // something is still waiting: this bucket is full and spilled
+                bw[CQ_BW_KEY_LO] |= 1u;
+                o.overflowed++;
+            } else if (until_drained) { o.stopped_at = b + 1; return; }
         }
+        // leftovers, oldest first
+        o.left.assign(carry.begin() + (ptrdiff_t)qpos, carry.end());
+        o.left.insert(o.left.end(), E + cl, E + nx);
+    };
+    std::vector<SweepOut> outs(kParts);
+    {
+        std::atomic<unsigned> nextp{0};
+        const std::vector<Entry> none;
+        parallel_for(worker_count(img.n_buckets_alloc), [&](unsigned) {
+            for (;;) {
+                const unsigned p = nextp.fetch_add(1);
+                if (p >= kParts) break;
+                sweep(p, first_bucket(p), first_bucket(p + 1), none, false, outs[p]);
+            }
+        });
     }
-    size_t next = 0;         // next entry not yet pulled into the carry
-    size_t carry_lo = 0;     // entries [carry_lo, next) are waiting for a slot, oldest first
     uint64_t overflowed = 0;
-    for (uint64_t b = 0; b < img.n_buckets_alloc; b++) {
-        while (next < w && ent[next].home <= b) next++;
-        size_t avail = next - carry_lo;
-        if (avail == 0) {
-            if (next >= w) break;
-            continue;
+    for (unsigned p = 0; p < kParts; p++) {
+        if (p + 1 < kParts && !outs[p].left.empty()) {   // redo the head of part p+1 with the carry of part p
+            SweepOut redo;
+            redo.overflowed = 0;
+            const std::vector<Entry> carry = std::move(outs[p].left);
+            sweep(p + 1, first_bucket(p + 1), first_bucket(p + 2), carry, true, redo);
+            outs[p + 1].overflowed += redo.overflowed;   // may be "negative": flags of the redone buckets are taken back
+            outs[p + 1].max_chain = std::max(outs[p + 1].max_chain, redo.max_chain);
+            if (redo.stopped_at == first_bucket(p + 2)) outs[p + 1].left = std::move(redo.left);   // ran through: its carry replaces the old one
         }
-        size_t take = std::min<size_t>(avail, CQ_SLOTS_PER_BUCKET);
-        uint32_t *bw = &img.table[b * CQ_BUCKET_WORDS];
-        for (size_t k = 0; k < take; k++) {
-            const Entry &e = ent[carry_lo + k];
-            uint32_t lo = (uint32_t)e.key, hi = (uint32_t)(e.key >> 32);
-            if (k == 0) {   // slot 0 lends bit 0 of key_lo to the overflow flag
-                if (lo & 1u) hi |= CQ_SLOT0_BIT0_IN_HI;
-                lo &= ~1u;
-            }
-            bw[CQ_BW_KEY_LO + k] = lo;
-            bw[CQ_BW_KEY_HI + k] = hi;
-            bw[CQ_BW_VAL_U + k] = e.val_u;
-            bw[CQ_BW_VAL_D + k] = e.val_d;
-            uint32_t chain = (uint32_t)(b - e.home) + 1;
-            if (chain > img.max_chain) img.max_chain = chain;
-        }
-        carry_lo += take;
-        if (carry_lo < next) {  // something is still waiting: this bucket is full and spilled
-            bw[CQ_BW_KEY_LO] |= 1u;
-            overflowed++;
-        }
+        overflowed += outs[p].overflowed;
+        img.max_chain = std::max(img.max_chain, outs[p].max_chain);
     }
-    if (carry_lo < w) { err = "spill tail exhausted while laying out the table"; return CQ_ERR_LIMIT; }
+    if (!outs[kParts - 1].left.empty()) { err = "spill tail exhausted while laying out the table"; return CQ_ERR_LIMIT; }
     img.n_overflowed = overflowed;
+    st.lap("placement sweep");
     return CQ_OK;
 }
 

@@ -298,3 +298,36 @@ def test_image_cache_roundtrip_and_invalidation(name, tmp_path, monkeypatch):
     # opting out again never reads it
     monkeypatch.delenv("CAMMIQ_IMAGE_CACHE")
     assert cq.Index(pu, pd, device=-1).info.reserved_ == 0
+
+
+@pytest.mark.parametrize("name", ["f_deep", "survey_F2"])
+def test_parallel_layout_equals_serial_layout(name, tmp_path, monkeypatch):
+    """The table is laid out by 256 independent part sweeps plus a boundary fix-up
+    (cq_layout.cpp); the image must be byte-identical to the one a single serial sweep gives,
+    for any number of workers and any table density (dense tables spill across part borders)."""
+    import shutil
+    g = golden(name)
+    monkeypatch.setenv("CAMMIQ_IMAGE_CACHE", "1")
+    images = {}
+    for kpb in ("1.0", "3.0", "3.9"):
+        for threads in ("1", "3", "8"):
+            d = tmp_path / f"k{kpb}_t{threads}"
+            d.mkdir()
+            pu = str(d / "index_u.bin1")
+            pd = str(d / "index_d.bin2") if g["pd"] else None
+            for src, dst in ((g["pu"], pu), (g["pd"], pd)):
+                if src:
+                    shutil.copy2(src, dst)
+                    shutil.copy2(src + ".aux", dst + ".aux")
+            monkeypatch.setenv("CAMMIQ_LAYOUT_THREADS", threads)
+            monkeypatch.setenv("CAMMIQ_KEYS_PER_BUCKET", kpb)
+            ix = cq.Index(pu, pd, device=-1)
+            raw = open(pu + ".cqimg", "rb").read()
+            # skip the header (source mtimes differ between the copies only if copy2 failed to keep them)
+            images.setdefault(kpb, []).append((ix.info_dict(), raw))
+        ref = images[kpb][0]
+        for other in images[kpb][1:]:
+            assert other[0] == ref[0]
+            assert other[1] == ref[1], f"kpb {kpb}: parallel layout differs from the serial one"
+    # the dense layouts really did spill (otherwise the fix-up path was not exercised)
+    assert images["3.9"][0][0]["n_overflowed"] > images["1.0"][0][0]["n_overflowed"]
