@@ -347,11 +347,12 @@ __device__ __forceinline__ void decide(const QueryArgs &a, const Tile &t, uint32
     const uint32_t *gid = t.hit_gid + rl * CAP, *r1 = t.hit_r1 + rl * CAP, *r2 = t.hit_r2 + rl * CAP;
     uint32_t nU = 0, u0 = 0, nP = 0, pa = 0, pb = 0, ia = 0, ib = 0;
     bool va = false, vb = false;
+    uint32_t dupmask = 0;                   // CAP <= 32: bit i = hit i repeats an earlier leaf
     for (uint32_t i = 0; i < n; i++) {
         const uint32_t g = gid[i];
         bool dup = false;
         for (uint32_t j = 0; j < i; j++) dup |= (gid[j] == g);   // pnodes is a set (query.cpp:465)
-        if (dup) continue;
+        if (dup) { if (CAP <= 32) dupmask |= 1u << i; continue; }
         const uint32_t x = r1[i], y = r2[i];
         if (y == 0) {                       // rids.insert(refID1)
             if (nU == 0) { u0 = x; nU = 1; }
@@ -390,8 +391,8 @@ __device__ __forceinline__ void decide(const QueryArgs &a, const Tile &t, uint32
     if (counted && a.mode == CQ_MODE_P && a.rcount && CQ_EXP != 5) {
         for (uint32_t i = 0; i < n; i++) {
             const uint32_t g = gid[i];
-            bool dup = false;
-            for (uint32_t j = 0; j < i; j++) dup |= (gid[j] == g);
+            bool dup = CAP <= 32 && ((dupmask >> (i & 31u)) & 1u);
+            if (CAP > 32) for (uint32_t j = 0; j < i; j++) dup |= (gid[j] == g);
             if (!dup) atomicAdd(&a.rcount[g], 1u);               // pn->rcount += 1
         }
     }
