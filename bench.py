@@ -5,12 +5,16 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-One "step" = one pass of the hot path (what FqReader::query64mt_p does for one FASTQ,
-/root/reference/src/query.cpp:650-889) over one batch of synthetic reads that is already
-resident in HBM: reset counters, classify kernel(s), and for N > 1 the RCCL all-reduce of the
-count vectors (issued asynchronously: it overlaps the next step's kernel, all of them are
-complete before the clock stops).  Index load / layout and FASTQ parsing are outside the bracket, exactly like
-the reference's own `Time for query` line (query.cpp:459,645-647).
+One "step" = one pass of the hot path (what FqReader::query64mt_p does for the reads of one
+FASTQ, /root/reference/src/query.cpp:650-889) over one batch of synthetic reads that is already
+resident in HBM: the classify kernel(s), accumulating into the device counters like the reference
+accumulates into FqReader state.  The K timed steps are the K batches of one query; for N > 1 the
+query ends with its one real exchange step, the RCCL all-reduce of the count vectors and of rcount
+(BASELINE.json north_star: "count vectors all-reduced ... before the host hands the count matrix to
+the ILP"), INSIDE the timed bracket.  --allreduce-every-step instead treats every batch as a query
+of its own (reset, classify, all-reduce; the collective of step i is issued asynchronously and
+overlaps the kernel of step i+1).  Index load / layout and FASTQ parsing are outside the bracket,
+exactly like the reference's own `Time for query` line (query.cpp:459,645-647).
 
 Workload at N = 1 = BASELINE.json configs[1]: 500 synthetic bacterial-size genomes, --unique
 index (h = k = 26), 10 M x 100 bp reads.  N > 1 is weak scaling: the index is replicated and
@@ -56,6 +60,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true",
                     help="skip the CPU oracle leg and its parity gate (used under rocprofv3 so that every "
                          "classify launch in the trace is a full-size timed step)")
+    ap.add_argument("--allreduce-every-step", action="store_true",
+                    help="N > 1: reset + all-reduce the counters every step (every batch its own query) instead of "
+                         "once per run")
     ap.add_argument("--host-api", action="store_true",
                     help="also time cq_query on host ASCII reads (PCIe-inclusive rate; never `value`)")
     args = ap.parse_args()
@@ -121,28 +128,35 @@ def main():
         sw = packed.shape[1]
         d_packed = torch.from_numpy(packed.view(np.int32)).cuda()
         d_lens = torch.from_numpy(lens).cuda()
-        # two sets of counters: the all-reduce of step i overlaps the classify kernel of step i+1
-        # (independent batches, like consecutive FASTQ files of one run)
+        # two sets of counters: with --allreduce-every-step the all-reduce of step i overlaps the classify
+        # kernel of step i+1 (independent batches, like consecutive FASTQ files of one run)
         ctrs = [torch.zeros(ix.counter_words(G), dtype=torch.int64, device="cuda") for _ in range(2)]
         rcs = [torch.zeros(max(nu + nd, 1), dtype=torch.int32, device="cuda") for _ in range(2)]
         pending = [None, None]
         stream = torch.cuda.current_stream().cuda_stream
         step_no = [0]
+        per_step = args.allreduce_every_step and world > 1
 
         def step():
-            b = step_no[0] & 1
+            b = (step_no[0] & 1) if per_step else 0
             step_no[0] += 1
-            if pending[b] is not None:
-                for wk in pending[b]:
-                    wk.wait()                 # the collective that last used this buffer pair
-                pending[b] = None
-            ctrs[b].zero_()                   # resetCounters (query.cpp:1820-1840)
-            rcs[b].zero_()
+            if per_step:
+                if pending[b] is not None:
+                    for wk in pending[b]:
+                        wk.wait()             # the collective that last used this buffer pair
+                    pending[b] = None
+                ctrs[b].zero_()               # resetCounters (query.cpp:1820-1840)
+                rcs[b].zero_()
             ix.query_device(cq.MODE_P, d_packed.data_ptr(), d_lens.data_ptr(), n, sw, args.read_len, G,
-                            ctrs[b].data_ptr(), rcs[b].data_ptr(), stream)
-            if world > 1:
+                            ctrs[b].data_ptr(), rcs[b].data_ptr(), stream)   # accumulates
+            if per_step:
                 pending[b] = cqdist.allreduce_counts(ctrs[b], rcs[b], async_op=True)
             return b
+
+        def finish_query():
+            """End of a query: the one exchange step (N > 1, unless every step already had its own)."""
+            if world > 1 and not per_step:
+                cqdist.allreduce_counts(ctrs[0], rcs[0])
 
         def fence():
             for b in (0, 1):
@@ -156,6 +170,11 @@ def main():
 
         for _ in range(args.warmup):
             step()
+        finish_query()                        # also warms RCCL up
+        fence()
+        for b in (0, 1):                      # resetCounters before the timed query
+            ctrs[b].zero_()
+            rcs[b].zero_()
         fence()
         kms = []
         last = 0
@@ -163,6 +182,7 @@ def main():
         for _ in range(args.steps):
             last = step()
             kms.append(ix.last_kernel_ms())   # HIP events on the launch stream, recorded inside the library
+        finish_query()
         fence()
         dt = time.perf_counter() - t0
         if world > 1:
@@ -170,14 +190,16 @@ def main():
             tdist.all_reduce(tmax, op=tdist.ReduceOp.MAX)
             dt = float(tmax.item())
         ctr = ctrs[last]
+        counted_steps = 1 if per_step else args.steps   # how many batches the final counters hold
 
         # ---- sanity on the last step's counters: every read lands in exactly one outcome
         c = ctr.cpu().numpy().astype(np.uint64)
         tot_reads = n * world
+        held_reads = tot_reads * counted_steps
         nundet, nconf, nskip, nslow = (int(c[2 * (G + 1) + i]) for i in (0, 1, 2, 4))
         cnt_u_sum = int(c[:G + 1].sum())
         if not args.both and not os.environ.get("CAMMIQ_LIB"):
-            assert cnt_u_sum + nundet + nconf + nskip == tot_reads, "conservation of reads violated"
+            assert cnt_u_sum + nundet + nconf + nskip == held_reads, "conservation of reads violated"
 
         result = None
         if rank == 0:
@@ -208,14 +230,17 @@ def main():
                            "index_device_GB": round(info["device_bytes"] / 1e9, 3),
                            "table_buckets_overflowed": info["n_overflowed"], "table_max_chain": info["max_chain"],
                            "parallelism": f"reads sharded x{world}, index replicated" +
-                                          (", RCCL all-reduce of counts + rcount per step, overlapped with the next step's kernel" if world > 1 else "")},
+                                          ((", RCCL all-reduce of counts + rcount per step, overlapped with the next step's kernel"
+                                            if per_step else
+                                            ", one RCCL all-reduce of counts + rcount at the end of the query, inside the timed bracket")
+                                           if world > 1 else "")},
                 "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                              "kernel": "classify_kernel<8,16,false>", "kernel_ms": round(k_ms, 4),
                              "algorithmic_bytes_per_read": B},
                 "kernel_Mreads_s": round(n / (k_ms * 1e-3) / 1e6, 3),
-                "outcome": {"nundet": nundet, "nconf": nconf, "nskipped": nskip, "slow_path_reads": nslow,
-                            "cnt_u_sum": cnt_u_sum},
+                "outcome": {"reads": held_reads, "nundet": nundet, "nconf": nconf, "nskipped": nskip,
+                            "slow_path_reads": nslow, "cnt_u_sum": cnt_u_sum},
                 "setup_s": {"generate": round(t_gen, 2), "index_load_layout_upload": round(t_load, 2),
                             "pack_reads": round(t_pack, 2)},
             }
@@ -230,7 +255,8 @@ def main():
             result["host_api"] = {"Mreads_s": round(n / th / 1e6, 2), "seconds": round(th, 4),
                                   "what": "cq_query on ASCII reads in pageable host memory, counters back on the host "
                                           "(pack + H2D + kernel + D2H, 2 M-read chunks double-buffered)"}
-            assert int(hq["cnt_u"].sum()) == cnt_u_sum and hq["nundet"] == nundet, "host API disagrees with device API"
+            assert int(hq["cnt_u"].sum()) * counted_steps == cnt_u_sum and hq["nundet"] * counted_steps == nundet, \
+                "host API disagrees with device API"
 
         # ---- CPU baseline (rank 0, N = 1 only): the oracle, a restatement of query64mt_p
         if rank == 0 and world == 1 and not args.no_cpu_baseline and args.cpu_sample > 0:
