@@ -19,6 +19,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <future>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -293,6 +294,19 @@ int main(int argc, char **argv)
         list_fastq(fq_dir, fq_names);
     }
 
+    // FASTQ parsing does not need the index: file f+1 is parsed on a second thread while the index loads
+    // (f = 0) or while file f is being classified.  (The reference reads and queries strictly in turn,
+    // query.cpp:371-425; the stderr lines keep its order.)
+    struct Parsed { std::vector<uint8_t> bases; std::vector<uint64_t> offs; };
+    auto parse_async = [&](size_t f) {
+        return std::async(std::launch::async, [&, f] {
+            Parsed p;
+            read_fastq(fq_names[f], min_rl, p.bases, p.offs);
+            return p;
+        });
+    };
+    std::future<Parsed> next_fq = parse_async(0);
+
     auto t0 = std::chrono::high_resolution_clock::now();
     cq_index *ix = nullptr;
     if (cq_index_load(fi1.c_str(), fi2.empty() ? nullptr : fi2.c_str(), device, &ix) != CQ_OK) {
@@ -317,12 +331,13 @@ int main(int argc, char **argv)
         cq_index_leaves(ix, tb, leaves[tb].data());
     }
 
-    std::vector<uint8_t> bases;
-    std::vector<uint64_t> offs;
     std::vector<uint64_t> cu(G + 1), cd(G + 1), pc(1 << 16);
     std::vector<uint32_t> ru(info.n_leaves[0]), rd(info.n_leaves[1]), pa(1 << 16), pb(1 << 16);
     for (size_t f = 0; f < fq_names.size(); f++) {
-        read_fastq(fq_names[f], min_rl, bases, offs);
+        Parsed fq = next_fq.get();
+        if (f + 1 < fq_names.size()) next_fq = parse_async(f + 1);
+        const std::vector<uint8_t> &bases = fq.bases;
+        const std::vector<uint64_t> &offs = fq.offs;
         const std::string cur = base_name(fq_names[f]);
         if (id_mode && t > 1) fprintf(stderr, "Single cell queries only support one thread.\n");
         fprintf(stderr, "Querying %s.\n", cur.c_str());
