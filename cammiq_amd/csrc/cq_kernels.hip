@@ -56,6 +56,9 @@ constexpr int kWaves = kBlock / 64;
 #ifndef CQ_WORK_DRAIN
 #define CQ_WORK_DRAIN 64
 #endif
+#ifndef CQ_NT_ROWS
+#define CQ_NT_ROWS 1   /* read rows are a read-once stream: nontemporal loads keep them from displacing buckets in L2 */
+#endif
 #ifndef CQ_EXP
 #define CQ_EXP 0   /* diagnostic builds only (wrong results): 1 no exact lookups, 2 no bucket chains, 3 no decision, 4 lookups stop after the first bucket, 5 no rcount atomics, 6 hits resolved but not recorded */
 #endif
@@ -448,7 +451,15 @@ classify_kernel(DevIndex ix, QueryArgs a)
         if (sub >= n_sub) return;
         const uint64_t r0 = sub * R;
         const uint32_t nr = (uint32_t)((n_reads - r0) < (uint64_t)R ? (n_reads - r0) : (uint64_t)R);
+#if CQ_NT_ROWS
+        if (lane < nr * (sw >> 2)) {
+            const uint32_t *src = a.packed + r0 * sw + lane * 4;
+            pf_row = make_uint4(__builtin_nontemporal_load(src), __builtin_nontemporal_load(src + 1),
+                                __builtin_nontemporal_load(src + 2), __builtin_nontemporal_load(src + 3));
+        }
+#else
         if (lane < nr * (sw >> 2)) pf_row = ((const uint4 *)(a.packed + r0 * sw))[lane];
+#endif
         if (lane < nr) pf_len = a.lens[r0 + lane];
     };
     if (!SLOW) prefetch(wave_gid);
