@@ -20,6 +20,7 @@
 #include <algorithm>
 #include <chrono>
 #include <future>
+#include <memory>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -85,11 +86,25 @@ std::vector<Genome> load_map(const std::string &fn)
 // reference seeds rand() from the clock, so its output on reads with N is not reproducible;
 // this shell derives the base from the read's index instead (documented deviation).
 // Unlike the reference (one getline + one new[] per read, single thread) the file is
-// memory-mapped and split at line boundaries across threads: count lines, prefix-sum, then
-// copy the sequence lines into one contiguous buffer + offsets, which is what cq_query takes.
-void read_fastq(const std::string &fn, size_t min_l, std::vector<uint8_t> &bases, std::vector<uint64_t> &offs)
+// memory-mapped and split at line boundaries across threads.  Two passes: (1) every chunk counts
+// its lines and, for each of the four possible positions of its first line in a FASTQ record, the
+// sequence lines and their bytes it would contribute; a prefix sum over the chunks then fixes
+// everything; (2) every chunk copies its sequence lines into one contiguous buffer + offsets,
+// which is what cq_query takes.  The output buffers are not initialised first (their pages are
+// first touched by the copying threads).
+struct Reads {
+    std::unique_ptr<uint8_t[]> bases;
+    std::unique_ptr<uint64_t[]> offs;   // n_reads + 1
+    size_t n_reads = 0, n_bases = 0;
+};
+
+void read_fastq(const std::string &fn, size_t min_l, Reads &out)
 {
-    bases.clear(); offs.assign(1, 0);
+    const bool timing = getenv("CAMMIQ_LOAD_TIMING") != nullptr;
+    const auto t_begin = std::chrono::steady_clock::now();
+    out = Reads();
+    out.offs.reset(new uint64_t[1]);
+    out.offs[0] = 0;
     int fd = open(fn.c_str(), O_RDONLY);
     if (fd < 0) die("Failed to find input file %s.\n", fn.c_str());
     struct stat st;
@@ -109,65 +124,75 @@ void read_fastq(const std::string &fn, size_t min_l, std::vector<uint8_t> &bases
         const char *nl = (const char *)memchr(p + q, '\n', n - q);
         cut[c] = nl ? (size_t)(nl - p) + 1 : n;
     }
-    std::vector<uint64_t> nlines(T, 0);
     auto for_chunks = [&](auto &&fn_) {
         std::vector<std::thread> th;
         for (unsigned c = 0; c < T; c++) th.emplace_back(fn_, c);
         for (auto &x : th) x.join();
     };
+    // pass 1: lines per chunk; kept reads / bytes for each residue (line number within the chunk) mod 4
+    struct Count { uint64_t lines = 0, reads[4] = {0, 0, 0, 0}, bytes[4] = {0, 0, 0, 0}; };
+    std::vector<Count> cnt(T);
     for_chunks([&](unsigned c) {
-        uint64_t k = 0;
+        Count k;
         for (const char *s = p + cut[c], *e = p + cut[c + 1]; s < e;) {
             const char *nl = (const char *)memchr(s, '\n', (size_t)(e - s));
-            k++;
+            size_t len = nl ? (size_t)(nl - s) : (size_t)(e - s);
+            if (len && s[len - 1] == '\r') len--;
+            if (len >= min_l) { k.reads[k.lines & 3u]++; k.bytes[k.lines & 3u] += len; }
+            k.lines++;
             if (!nl) break;
             s = nl + 1;
         }
-        nlines[c] = k;
+        cnt[c] = k;
     });
-    std::vector<uint64_t> line0(T + 1, 0);
-    for (unsigned c = 0; c < T; c++) line0[c + 1] = line0[c] + nlines[c];
-    // pass 2a: per chunk, kept reads and their total length
-    std::vector<uint64_t> nreads(T, 0), nbytes(T, 0);
-    auto walk = [&](unsigned c, auto &&emit) {
-        uint64_t li = line0[c];
+    // a chunk whose first line is line L of the file holds its sequence lines at residue (1 - L) mod 4
+    std::vector<uint64_t> line0(T + 1, 0), r0(T + 1, 0), b0(T + 1, 0);
+    for (unsigned c = 0; c < T; c++) {
+        const unsigned res = (unsigned)((1u - (unsigned)(line0[c] & 3u)) & 3u);
+        line0[c + 1] = line0[c] + cnt[c].lines;
+        r0[c + 1] = r0[c] + cnt[c].reads[res];
+        b0[c + 1] = b0[c] + cnt[c].bytes[res];
+    }
+    out.n_reads = r0[T];
+    out.n_bases = b0[T];
+    out.bases.reset(new uint8_t[out.n_bases ? out.n_bases : 1]);
+    out.offs.reset(new uint64_t[out.n_reads + 1]);
+    out.offs[out.n_reads] = out.n_bases;
+    // pass 2: copy
+    const char alphabet[4] = {'A', 'C', 'G', 'T'};
+    uint8_t *const bases = out.bases.get();
+    uint64_t *const offs = out.offs.get();
+    for_chunks([&](unsigned c) {
+        uint64_t r = r0[c], b = b0[c], li = line0[c];
         for (const char *s = p + cut[c], *e = p + cut[c + 1]; s < e; li++) {
             const char *nl = (const char *)memchr(s, '\n', (size_t)(e - s));
             size_t len = nl ? (size_t)(nl - s) : (size_t)(e - s);
             if ((li & 3u) == 1u) {
                 if (len && s[len - 1] == '\r') len--;
-                if (len >= min_l) emit(s, len, li >> 2);
+                if (len >= min_l) {
+                    offs[r++] = b;
+                    uint8_t *dst = bases + b;
+                    memcpy(dst, s, len);
+                    if (memchr(dst, 'N', len)) {
+                        uint64_t z = ((li >> 2) + 1) * 0x9E3779B97F4A7C15ull;
+                        z ^= z >> 29;
+                        const uint8_t sub = (uint8_t)alphabet[(z >> 7) & 3];
+                        for (size_t i = 0; i < len; i++) if (dst[i] == 'N') dst[i] = sub;
+                    }
+                    b += len;
+                }
             }
             if (!nl) break;
             s = nl + 1;
         }
-    };
-    for_chunks([&](unsigned c) { walk(c, [&](const char *, size_t len, uint64_t) { nreads[c]++; nbytes[c] += len; }); });
-    std::vector<uint64_t> r0(T + 1, 0), b0(T + 1, 0);
-    for (unsigned c = 0; c < T; c++) { r0[c + 1] = r0[c] + nreads[c]; b0[c + 1] = b0[c] + nbytes[c]; }
-    bases.resize(b0[T]);
-    offs.resize(r0[T] + 1);
-    offs[r0[T]] = b0[T];
-    // pass 2b: copy
-    const char alphabet[4] = {'A', 'C', 'G', 'T'};
-    for_chunks([&](unsigned c) {
-        uint64_t r = r0[c], b = b0[c];
-        walk(c, [&](const char *s, size_t len, uint64_t rec) {
-            offs[r++] = b;
-            uint8_t *dst = bases.data() + b;
-            memcpy(dst, s, len);
-            if (memchr(dst, 'N', len)) {
-                uint64_t z = (rec + 1) * 0x9E3779B97F4A7C15ull;
-                z ^= z >> 29;
-                const uint8_t sub = (uint8_t)alphabet[(z >> 7) & 3];
-                for (size_t i = 0; i < len; i++) if (dst[i] == 'N') dst[i] = sub;
-            }
-            b += len;
-        });
     });
     munmap((void *)p, n);
     close(fd);
     fprintf(stderr, "Loaded query file %s.\n", fn.c_str());
+    if (timing)
+        fprintf(stderr, "[read_fastq] %.1f ms for %.2f GB, %zu reads, %u threads\n",
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(), n / 1e9,
+                out.n_reads, T);
 }
 
 void list_fastq(const std::string &dir, std::vector<std::string> &out)
@@ -224,12 +249,12 @@ int main(int argc, char **argv)
         }
         if (v == "--fastq_stats") {   // diagnostic: parse one FASTQ like a query would, print a digest, exit
             const char *f = need(i, "Please specify a fastq file.\n");
-            std::vector<uint8_t> b; std::vector<uint64_t> o;
-            read_fastq(f, min_rl, b, o);
+            Reads rd;
+            read_fastq(f, min_rl, rd);
             uint64_t hsh = 1469598103934665603ull;
-            for (uint8_t c : b) hsh = (hsh ^ c) * 1099511628211ull;
-            for (uint64_t x : o) hsh = (hsh ^ x) * 1099511628211ull;
-            printf("reads %zu bases %zu fnv %016llx\n", o.size() - 1, b.size(), (unsigned long long)hsh);
+            for (size_t k = 0; k < rd.n_bases; k++) hsh = (hsh ^ rd.bases[k]) * 1099511628211ull;
+            for (size_t k = 0; k <= rd.n_reads; k++) hsh = (hsh ^ rd.offs[k]) * 1099511628211ull;
+            printf("reads %zu bases %zu fnv %016llx\n", rd.n_reads, rd.n_bases, (unsigned long long)hsh);
             return 0;
         }
         if (v == "--device") { device = atoi(need(i, "Please specify the GPU ordinal.\n")); continue; }
@@ -297,15 +322,14 @@ int main(int argc, char **argv)
     // FASTQ parsing does not need the index: file f+1 is parsed on a second thread while the index loads
     // (f = 0) or while file f is being classified.  (The reference reads and queries strictly in turn,
     // query.cpp:371-425; the stderr lines keep its order.)
-    struct Parsed { std::vector<uint8_t> bases; std::vector<uint64_t> offs; };
     auto parse_async = [&](size_t f) {
         return std::async(std::launch::async, [&, f] {
-            Parsed p;
-            read_fastq(fq_names[f], min_rl, p.bases, p.offs);
+            Reads p;
+            read_fastq(fq_names[f], min_rl, p);
             return p;
         });
     };
-    std::future<Parsed> next_fq = parse_async(0);
+    std::future<Reads> next_fq = parse_async(0);
 
     auto t0 = std::chrono::high_resolution_clock::now();
     cq_index *ix = nullptr;
@@ -334,10 +358,8 @@ int main(int argc, char **argv)
     std::vector<uint64_t> cu(G + 1), cd(G + 1), pc(1 << 16);
     std::vector<uint32_t> ru(info.n_leaves[0]), rd(info.n_leaves[1]), pa(1 << 16), pb(1 << 16);
     for (size_t f = 0; f < fq_names.size(); f++) {
-        Parsed fq = next_fq.get();
+        Reads fq = next_fq.get();
         if (f + 1 < fq_names.size()) next_fq = parse_async(f + 1);
-        const std::vector<uint8_t> &bases = fq.bases;
-        const std::vector<uint64_t> &offs = fq.offs;
         const std::string cur = base_name(fq_names[f]);
         if (id_mode && t > 1) fprintf(stderr, "Single cell queries only support one thread.\n");
         fprintf(stderr, "Querying %s.\n", cur.c_str());
@@ -347,9 +369,9 @@ int main(int argc, char **argv)
         c.cnt_u = cu.data(); c.cnt_d = cd.data();
         c.rcount_u = ru.empty() ? nullptr : ru.data(); c.rcount_d = rd.empty() ? nullptr : rd.data();
         c.pair_a = pa.data(); c.pair_b = pb.data(); c.pair_cnt = pc.data(); c.pair_cap = pc.size();
-        int rc = cq_query(ix, id_mode ? CQ_MODE_SC : CQ_MODE_P, bases.data(), offs.data(), offs.size() - 1, G, &c);
+        int rc = cq_query(ix, id_mode ? CQ_MODE_SC : CQ_MODE_P, fq.bases.get(), fq.offs.get(), fq.n_reads, G, &c);
         if (rc != CQ_OK) { fprintf(stderr, "%s\n", cq_last_error()); return EXIT_FAILURE; }
-        fprintf(stderr, "Processed %lu reads.\r", (unsigned long)(offs.size() - 1));
+        fprintf(stderr, "Processed %lu reads.\r", (unsigned long)fq.n_reads);
         fprintf(stderr, "\nNumber of unlabeled reads: %lu.\n", (unsigned long)c.nundet);
         fprintf(stderr, "Number of reads with conflict labels: %lu.\n", (unsigned long)c.nconf);
         if (c.nskipped) fprintf(stderr, "Number of reads outside the supported domain (skipped): %lu.\n", (unsigned long)c.nskipped);

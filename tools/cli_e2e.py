@@ -51,11 +51,15 @@ try:
         t0 = time.time()
         r = subprocess.run([os.path.join(ROOT, "cammiq_amd", "cammiq"), "--query", "--read_cnts", "-f",
                             os.path.join(wdir, "genome_map.out"), "-i", pu, "-q", fq, "-o", out] + extra,
-                           capture_output=True, text=True)
+                           capture_output=True, text=True, env=dict(os.environ, CAMMIQ_LOAD_TIMING="1"))
         wall = time.time() - t0
         assert r.returncode == 0, r.stderr[-2000:]
-        return wall, {ln.split(":")[0].strip(): ln.split(":")[1].strip() for ln in r.stderr.splitlines()
-                      if ln.startswith("Time for")}
+        times = {ln.split(":")[0].strip(): ln.split(":")[1].strip() for ln in r.stderr.splitlines()
+                 if ln.startswith("Time for")}
+        for ln in r.stderr.splitlines():
+            if ln.startswith("[read_fastq]"):
+                times["read_fastq"] = ln[len("[read_fastq]"):].strip()
+        return wall, times
     wall, times = run_cli([])
     run_cli(["--image_cache"])                      # writes <index_u>.cqimg
     wall_cached, times_cached = run_cli(["--image_cache"])
