@@ -209,7 +209,6 @@ int build_image(const DecodedTable &u, const DecodedTable &d, double keys_per_bu
     // the device gets the path-compressed form (bucket roots are compressed where they are used)
     img.nodes.clear();
     img.nodes.push_back(Node{{0, 0, 0, 0}});
-    Compressor comp{linked, img.nodes};
 
     img.leaf_r1.resize(nu + nd);
     img.leaf_r2.resize(nu + nd);
@@ -255,11 +254,37 @@ int build_image(const DecodedTable &u, const DecodedTable &d, double keys_per_bu
                 if (code && !(code & CQ_LEAF_BIT)) deep[t].push_back(i);
             }
         });
-        for (unsigned t = 0; t < nte; t++)
+        // Path compression, every worker on its own slice of the deep roots into its own node array
+        // (local index 0 = dummy, like the final array); the arrays are then concatenated in slice order --
+        // exactly the order a serial pass over the roots appends in -- and the local indices relocated.
+        std::vector<std::vector<Node>> local(nte);
+        parallel_for(nte, [&](unsigned t) {
+            local[t].push_back(Node{{0, 0, 0, 0}});
+            Compressor comp{linked, local[t]};
             for (uint64_t i : deep[t]) {
                 if (i < nb_u) ent[i].val_u = comp.run(ent[i].val_u);
                 else ent[i].val_d = comp.run(ent[i].val_d);
             }
+        });
+        std::vector<uint64_t> base(nte + 1, 1);   // global index of worker t's local node 1
+        for (unsigned t = 0; t < nte; t++) base[t + 1] = base[t] + (local[t].size() - 1);
+        if (base[nte] >= (1ull << 30)) { err = "more than 2^30 trie nodes after path compression"; return CQ_ERR_LIMIT; }
+        img.nodes.resize(base[nte]);
+        parallel_for(nte, [&](unsigned t) {
+            const uint32_t shift = (uint32_t)(base[t] - 1);   // local index k -> global index k + shift
+            auto reloc = [&](uint32_t code) { return (code == 0 || (code & CQ_LEAF_BIT)) ? code : code + shift; };
+            for (size_t k = 1; k < local[t].size(); k++) {
+                Node n = local[t][k];
+                if ((n.child[0] >> 30) == 1u) n.child[3] = reloc(n.child[3]);          // chain node: only `next` is a reference
+                else for (int c = 0; c < 4; c++) n.child[c] = reloc(n.child[c]);
+                img.nodes[base[t] - 1 + k] = n;
+            }
+            for (uint64_t i : deep[t]) {
+                if (i < nb_u) ent[i].val_u = reloc(ent[i].val_u);
+                else ent[i].val_d = reloc(ent[i].val_d);
+            }
+            std::vector<Node>().swap(local[t]);
+        });
     }
     st.lap("compress tries");
     // ... then the home buckets (a minimizer scan per key: the expensive part) on all cores
