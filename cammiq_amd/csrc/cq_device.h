@@ -16,6 +16,8 @@
 #define CQ_CHAIN_BIT 0x40000000u          /* word 0 of a path-compressed trie node: CQ_CHAIN_BIT | length */
 #define CQ_INLINE_RID_BIT 0x40000000u     /* slot val_d when ht_d has no such key and val_u is a unique leaf:
                                              CQ_INLINE_RID_BIT | refID1 of that leaf (saves the leaf_rids read) */
+#define CQ_INLINE_PAIR_BIT 0x40000000u    /* slot val_u when ht_u has no such key and val_d is a leaf whose two refIDs
+                                             are below 2^15: CQ_INLINE_PAIR_BIT | refID1 << 15 | refID2 */
 #define CQ_EMPTY_KEY 0xFFFFFFFFFFFFFFFFull
 #define CQ_KEY_MASK (~(3ull << 62))       /* h <= 31  =>  hv < 2^62 (query.cpp:482-485) */
 #define CQ_SLOTS_PER_BUCKET 4             /* 4 slots x 16 B = one 64-byte HBM access */
@@ -27,7 +29,7 @@
  *   word  0.. 3  key_lo[4]  low 32 bits of the 2h-bit packed h-mer (the reference's map64 key);
  *                           bit 0 of key_lo[0] is the bucket's OVERFLOW flag instead
  *   word  4.. 7  key_hi[4]  high 32 bits (< 2^30); bit 30 of key_hi[0] keeps slot 0's true bit 0
- *   word  8..11  val_u[4]   trie code of the bucket root in ht_u: 0 absent,
+ *   word  8..11  val_u[4]   trie code of the bucket root in ht_u: 0 absent (or CQ_INLINE_PAIR_BIT|refIDs, see above),
  *   word 12..15  val_d[4]   CQ_LEAF_BIT|global leaf id, or trie node index (same for ht_d;
  *                           or CQ_INLINE_RID_BIT|refID1, see above)
  *

@@ -272,6 +272,10 @@ __device__ __forceinline__ void resolve_pair(const DevIndex &ix, const Tile &t, 
         append_hit<CAP>(t, rl, v.x & ~CQ_LEAF_BIT, v.y & ~CQ_INLINE_RID_BIT, 0u);
         return;
     }
+    if ((v.x >> 30) == 1u) {                                       // CQ_INLINE_PAIR_BIT: a doubly-unique leaf, ht_d only
+        append_hit<CAP>(t, rl, v.y & ~CQ_LEAF_BIT, (v.x >> 15) & 0x7FFFu, v.x & 0x7FFFu);
+        return;
+    }
     if (v.x) resolve<CAP>(ix, t, row, len, rl, v.x, strand, p);   // ht_u
     if (v.y) resolve<CAP>(ix, t, row, len, rl, v.y, strand, p);   // ht_d
 }

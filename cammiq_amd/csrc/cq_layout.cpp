@@ -332,6 +332,12 @@ int build_image(const DecodedTable &u, const DecodedTable &d, double keys_per_bu
                         const uint32_t g = m.val_u & ~CQ_LEAF_BIT;
                         if (img.leaf_r2[g] == 0 && img.leaf_r1[g] < CQ_INLINE_RID_BIT) m.val_d = CQ_INLINE_RID_BIT | img.leaf_r1[g];
                     }
+                    // likewise a depth-0 leaf of ht_d alone: its two refIDs ride in the free val_u word
+                    if ((m.val_d & CQ_LEAF_BIT) && m.val_u == 0) {
+                        const uint32_t g = m.val_d & ~CQ_LEAF_BIT;
+                        if (img.leaf_r1[g] < (1u << 15) && img.leaf_r2[g] < (1u << 15))
+                            m.val_u = CQ_INLINE_PAIR_BIT | (img.leaf_r1[g] << 15) | img.leaf_r2[g];
+                    }
                     E[w++] = m;
                     i = j;
                 }
@@ -447,6 +453,7 @@ void image_lookup(const FlatImage &img, uint64_t key, uint32_t &val_u, uint32_t 
             if (lo == klo && hi == khi) {
                 val_u = bw[CQ_BW_VAL_U + k]; val_d = bw[CQ_BW_VAL_D + k];
                 if ((val_d >> 30) == 1u) val_d = 0;   // inline refID of the u leaf, not an ht_d entry
+                if ((val_u >> 30) == 1u) val_u = 0;   // inline refID pair of the d leaf, not an ht_u entry
                 if (chain_len) *chain_len = chain;
                 return;
             }
