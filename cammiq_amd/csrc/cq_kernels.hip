@@ -355,10 +355,14 @@ __device__ __forceinline__ void decide(const QueryArgs &a, const Tile &t, uint32
     uint32_t nU = 0, u0 = 0, nP = 0, pa = 0, pb = 0, ia = 0, ib = 0;
     bool va = false, vb = false;
     uint32_t dupmask = 0;                   // CAP <= 32: bit i = hit i repeats an earlier leaf
+    uint64_t seen = 0;                      // 64-bit filter over the leaf ids seen so far: the scan for an
+                                            // earlier copy runs only when the filter says there may be one
     for (uint32_t i = 0; i < n; i++) {
         const uint32_t g = gid[i];
+        const uint64_t bit = 1ull << (g & 63u);
         bool dup = false;
-        for (uint32_t j = 0; j < i; j++) dup |= (gid[j] == g);   // pnodes is a set (query.cpp:465)
+        if (seen & bit) for (uint32_t j = 0; j < i; j++) dup |= (gid[j] == g);   // pnodes is a set (query.cpp:465)
+        seen |= bit;
         if (dup) { if (CAP <= 32) dupmask |= 1u << i; continue; }
         const uint32_t x = r1[i], y = r2[i];
         if (y == 0) {                       // rids.insert(refID1)
