@@ -118,3 +118,35 @@ def test_fastq_loader_matches_independent_parse(tmp_path, n_reads, crlf, final_n
         assert r.returncode == 0, r.stderr
         n, b, h = _py_fastq_digest(str(fq), min_l)
         assert r.stdout.split() == ["reads", str(n), "bases", str(b), "fnv", "%016x" % h]
+
+
+@pytest.mark.gpu
+def test_cli_several_fastq_files(tmp_path):
+    """Three query files in one run: the next file is parsed while the previous one is classified;
+    every file gets its own TSV row and its own counters (the reference resets them per file,
+    query.cpp:1820-1840), equal to what each file gives alone."""
+    import cammiq_amd as cq
+    g = golden("survey_F1")
+    reads = g["reads"]
+    parts = [reads[:700], reads[700:701], reads[701:]]
+    names = []
+    for i, part in enumerate(parts):
+        fq = tmp_path / f"part{i}.fastq"
+        synth.write_fastq(str(fq), part)
+        names.append(str(fq))
+    out = tmp_path / "out.txt"
+    r = _run(["--query", "--read_cnts", "-f", os.path.join(g["dir"], "genome_map.out"), "-i", g["pu"], g["pd"],
+              "-q"] + names + ["-o", str(out)])
+    assert r.returncode == 0, r.stderr
+    lines = out.read_text().splitlines()
+    assert lines[0] == "QUERY/TAXID\t1001\t1002\t1003\t1004" and len(lines) == 4
+    ix = cq.Index(g["pu"], g["pd"], device=0)
+    total = [0, 0, 0, 0]
+    for i, part in enumerate(parts):
+        b, o = synth.concat_reads(part)
+        want = [int(x) for x in ix.query(b, o, g["G"], mode=cq.MODE_SC)["cnt_u"][1:]]
+        got = lines[1 + i].split("\t")
+        assert got[0] == f"part{i}.fastq" and [int(x) for x in got[1:]] == want
+        total = [a + c for a, c in zip(total, want)]
+    assert total == [412, 317, 404, 417]          # SURVEY.md 8(c): the whole sample
+    assert r.stderr.count("Time for query:") == 3 and r.stderr.count("Loaded query file") == 3
