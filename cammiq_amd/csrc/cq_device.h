@@ -54,7 +54,9 @@
  *     read the SAME 64-byte bucket and the memory system serves them with one HBM access.
  * Random HBM accesses per read drop from 2(rl-h+1) to about 2(rl-h+1)/(h-m+2)  (150 -> ~12
  * for rl=100, h=26); lookups stay exact because every slot still holds the full key. */
+#ifndef CQ_MAX_MINIMIZER
 #define CQ_MAX_MINIMIZER 16
+#endif
 
 CQ_HD uint32_t cq_minimizer_len(uint32_t h) { return h < CQ_MAX_MINIMIZER ? h : CQ_MAX_MINIMIZER; }
 
