@@ -331,3 +331,20 @@ def test_parallel_layout_equals_serial_layout(name, tmp_path, monkeypatch):
             assert other[1] == ref[1], f"kpb {kpb}: parallel layout differs from the serial one"
     # the dense layouts really did spill (otherwise the fix-up path was not exercised)
     assert images["3.9"][0][0]["n_overflowed"] > images["1.0"][0][0]["n_overflowed"]
+
+
+def test_header_is_plain_c99_and_the_abi_works_from_c(tmp_path):
+    """include/cammiq_hip.h compiles as strict C99 and the library is usable from plain C
+    (the boundary a cgo / JNI / ctypes binding would sit on)."""
+    import subprocess
+    exe = str(tmp_path / "abi_c99")
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "c", "abi_c99.c"), "-o", exe,
+                           "-L", os.path.join(ROOT, "cammiq_amd"), "-lcammiq_hip",
+                           "-Wl,-rpath," + os.path.join(ROOT, "cammiq_amd"), "-Wl,-rpath,/opt/rocm/lib"])
+    g = golden("f_deep")
+    r = subprocess.run([exe, g["pu"], g["pd"]], capture_output=True, text=True)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
+    ix = cq.Index(g["pu"], g["pd"], device=-1)
+    assert r.stdout.split() == ["ok", "hash_len", str(ix.hash_len), "leaves", f"{ix.n_leaves[0]}+{ix.n_leaves[1]}",
+                                "keys", str(ix.info.n_keys)]
