@@ -245,6 +245,11 @@ def test_benchmark_generator_world_matches_oracle(tmp_path, share):
         ref = oracle_lib.OracleIndex(pu, pd).query(b, o, 24, nthreads=8)
         assert_same(got, ref, f"bigsynth share={share} rl={rl}")
         assert got["nskipped"] == 0
+        if share:   # query64_sc on the same reads: counters and the (a, b) -> count map of read_cnts_b
+            got = cq.Index(pu, pd, device=0).query(b, o, 24, mode=cq.MODE_SC)
+            ref = oracle_lib.OracleIndex(pu, pd).query(b, o, 24, mode=1, nthreads=8)
+            assert_same(got, ref, f"bigsynth SC share={share} rl={rl}", rcount=False)
+            assert got["pairs"] == ref["pairs"] and len(ref["pairs"]) > 10
 
 
 def test_many_genomes_use_global_counters(tmp_path):
