@@ -5,20 +5,26 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-One "step" = one pass of the hot path (what FqReader::query64mt_p does for the reads of one
-FASTQ, /root/reference/src/query.cpp:650-889) over one batch of synthetic reads that is already
-resident in HBM: the classify kernel(s), accumulating into the device counters like the reference
-accumulates into FqReader state.  The K timed steps are the K batches of one query; for N > 1 the
-query ends with its one real exchange step, the RCCL all-reduce of the count vectors and of rcount
-(BASELINE.json north_star: "count vectors all-reduced ... before the host hands the count matrix to
-the ILP"), INSIDE the timed bracket.  --allreduce-every-step instead treats every batch as a query
-of its own (reset, classify, all-reduce; the collective of step i is issued asynchronously and
-overlaps the kernel of step i+1).  Index load / layout and FASTQ parsing are outside the bracket,
-exactly like the reference's own `Time for query` line (query.cpp:459,645-647).
+Workload at N = 1 = BASELINE.json configs[2] (the configuration north_star quotes the metric on):
+1000 synthetic bacterial-size genomes, --both index (unique + doubly-unique markers, h = k = 26),
+50 M x 100 bp reads per step.  `--config 1` runs configs[1] (500 genomes, --unique, 10 M reads).
+N > 1 is weak scaling (configs[3] shape): the index is replicated and every rank classifies its own
+50 M reads per step.
 
-Workload at N = 1 = BASELINE.json configs[1]: 500 synthetic bacterial-size genomes, --unique
-index (h = k = 26), 10 M x 100 bp reads.  N > 1 is weak scaling: the index is replicated and
-every rank classifies its own 10 M reads (configs[3] shape).  Prints ONE JSON line on rank 0.
+One "step" = one pass of the hot path (what FqReader::query64mt_p does for the reads of one FASTQ,
+/root/reference/src/query.cpp:650-889) over one batch of packed reads already resident in HBM: the
+classify kernels, accumulating into the device counters like the reference accumulates into FqReader
+state, plus the D2H copy of the counter block.  The K timed steps are the K batches of one query
+(three distinct resident batches, rotated); the query ends inside the timed bracket with its
+exchange step -- for N > 1 the RCCL all-reduce of the counter block and of rcount, issued by the
+product itself (cq_counts_allreduce, C ABI) -- and the D2H copy of rcount into pinned host memory,
+i.e. with everything the host hands to the ILP (query.cpp:251-258).  Index load / layout and FASTQ
+parsing are outside, exactly like the reference's own `Time for query` (query.cpp:459,645-647).
+
+`value` counts reads with the inputs resident in HBM when the clock starts.  The PCIe-inclusive
+rate of the same workload -- packed reads in pinned HOST memory, pipelined H2D + kernels + D2H
+through cq_query_packed, SURVEY.md 8(d)'s bracket -- is reported next to it as `host_fed`.
+Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
 
@@ -37,6 +43,12 @@ sys.path.insert(0, ROOT)
 
 METRIC = "Mreads/sec classified (100 bp, L=26); per-genome hit counts bit-exact"
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+GEN_CHUNK = 5_000_000  # reads generated + packed per piece (one reusable ASCII buffer)
+
+PRESETS = {
+    1: dict(genomes=500, both=False, reads=10_000_000, label="configs[1]"),
+    2: dict(genomes=1000, both=True, reads=50_000_000, label="configs[2]"),
+}
 
 
 def algorithmic_bytes_per_read(rl: int, h: int, tables: int) -> int:
@@ -44,28 +56,41 @@ def algorithmic_bytes_per_read(rl: int, h: int, tables: int) -> int:
     return (rl + 3) // 4 + 2 * (rl - h + 1) * tables * 16
 
 
+def workload_key(G, genome_len, both, n, rl):
+    return f"G{G}_L{genome_len}_{'both' if both else 'unique'}_n{n}_rl{rl}"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--genomes", type=int, default=500)
+    ap.add_argument("--config", type=int, default=2, choices=sorted(PRESETS),
+                    help="BASELINE.json configs[i]: 2 = 1000 genomes, --both, 50 M reads (default); 1 = 500, --unique, 10 M")
+    ap.add_argument("--genomes", type=int, default=None)
     ap.add_argument("--genome-len", type=int, default=3_450_000)
-    ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU per step")
+    ap.add_argument("--reads", type=int, default=None, help="reads per GPU per step")
     ap.add_argument("--read-len", type=int, default=100)
+    ap.add_argument("--batches", type=int, default=3, help="distinct resident batches the steps rotate over")
     ap.add_argument("--frac-deep", type=float, default=0.07,
                     help="fraction of markers longer than k (trie depth > 0); 0.07 is what the survey measured")
-    ap.add_argument("--both", action="store_true", help="unique + doubly-unique index (configs[2] shape)")
+    ap.add_argument("--both", action="store_true", default=None, help="unique + doubly-unique index")
+    ap.add_argument("--unique", dest="both", action="store_false", help="unique-only index")
     ap.add_argument("--cpu-sample", type=int, default=2_000_000, help="reads timed through the CPU oracle (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true",
                     help="skip the CPU oracle leg and its parity gate (used under rocprofv3 so that every "
                          "classify launch in the trace is a full-size timed step)")
-    ap.add_argument("--allreduce-every-step", action="store_true",
-                    help="N > 1: reset + all-reduce the counters every step (every batch its own query) instead of "
-                         "once per run")
-    ap.add_argument("--host-api", action="store_true",
-                    help="also time cq_query on host ASCII reads (PCIe-inclusive rate; never `value`)")
+    ap.add_argument("--no-host-fed", action="store_true", help="skip the PCIe-inclusive leg (cq_query_packed)")
+    ap.add_argument("--ascii-api", action="store_true",
+                    help="also time cq_query on ASCII reads in pageable memory (host packing included)")
     args = ap.parse_args()
+    preset = PRESETS[args.config]
+    G = args.genomes if args.genomes is not None else preset["genomes"]
+    both = preset["both"] if args.both is None else args.both
+    n = args.reads if args.reads is not None else preset["reads"]
+    is_preset = (G == preset["genomes"] and both == preset["both"] and n == preset["reads"] and args.read_len == 100
+                 and args.genome_len == 3_450_000)
+    label = preset["label"] if is_preset else f"configs[{args.config}]-shape (modified)"
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -81,9 +106,9 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the classify path has no CPU fallback")
-    # Rehearsal knob for a one-GPU box: CAMMIQ_BENCH_REHEARSAL=1 maps every rank to cuda:0 and uses
-    # gloo, so that the N > 1 code path (sharding, shared index files, all-reduce, max over ranks) can
-    # be exercised without an 8-GPU node.  Never set by the driver; numbers from it mean nothing.
+    # Rehearsal knob for a one-GPU box: CAMMIQ_BENCH_REHEARSAL=1 maps every rank to cuda:0 and reduces over
+    # gloo (RCCL needs one GPU per rank), so that the N > 1 code path (sharding, shared index files, max over
+    # ranks) can be exercised without an 8-GPU node.  Never set by the driver; numbers from it mean nothing.
     rehearsal = os.environ.get("CAMMIQ_BENCH_REHEARSAL") == "1"
     dev = 0 if rehearsal else local_rank
     torch.cuda.set_device(dev)
@@ -95,17 +120,17 @@ def main():
             tdist.init_process_group("nccl", device_id=torch.device("cuda", dev))
 
     h = k = 26
-    G = args.genomes
-    tables = 2 if args.both else 1
+    rl = args.read_len
+    tables = 2 if both else 1
     t_setup = time.time()
     # one copy of the index files per node: local rank 0 writes, the others wait
     shm = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
     wdir = os.path.join(shm, f"cammiq_bench_{os.environ.get('MASTER_PORT', os.getpid())}")
     try:
         w = bigsynth.World(seed=2, n_genomes=G, genome_len=args.genome_len, k=k, h=h, lmax=50,
-                           frac_deep=args.frac_deep, pair_share=0.3 if args.both else 0.0)
+                           frac_deep=args.frac_deep, pair_share=0.3 if both else 0.0)
         pu = os.path.join(wdir, "index_u.bin1")
-        pd = os.path.join(wdir, "index_d.bin2") if args.both else None
+        pd = os.path.join(wdir, "index_d.bin2") if both else None
         if local_rank == 0:
             os.makedirs(wdir, exist_ok=True)
             nu, nd = w.write_index(pu, pd)
@@ -119,51 +144,95 @@ def main():
         ix = cq.Index(pu, pd, device=dev)
         t_load = time.time() - t0
         info = ix.info_dict()
+        if local_rank == 0 and world == 1 and not (args.cpu_sample > 0 and not args.no_cpu_baseline):
+            shutil.rmtree(wdir, ignore_errors=True)    # the CPU leg is the only later reader of the files
 
-        n = args.reads
-        bases, offs = w.reads(seed=1000 + rank, n=n, length=args.read_len)
+        # ---- the batches: generated piecewise, packed once, resident in HBM (and, for the host-fed leg, in
+        #      page-locked host memory).  Batch j of rank r is read stream 1000 + 16 r + j of the generator.
+        host_fed = (world == 1 and not args.no_host_fed)
+        sw = cq.stride_words(rl)
+        nb = max(1, args.batches)
         t0 = time.time()
-        packed, lens, skipped = cq.pack_reads(bases, offs, h)
-        t_pack = time.time() - t0
-        sw = packed.shape[1]
-        d_packed = torch.from_numpy(packed.view(np.int32)).cuda()
-        d_lens = torch.from_numpy(lens).cuda()
-        # two sets of counters: with --allreduce-every-step the all-reduce of step i overlaps the classify
-        # kernel of step i+1 (independent batches, like consecutive FASTQ files of one run)
-        ctrs = [torch.zeros(ix.counter_words(G), dtype=torch.int64, device="cuda") for _ in range(2)]
-        rcs = [torch.zeros(max(nu + nd, 1), dtype=torch.int32, device="cuda") for _ in range(2)]
-        pending = [None, None]
+        ascii_buf = np.empty(min(GEN_CHUNK, n) * rl, np.uint8)
+        sample_bases = None
+        ns = min(args.cpu_sample, n)
+        h_packed, h_lens, d_packed, d_lens = [], [], [], []
+        for j in range(nb):
+            keep_host = host_fed and j == 0           # one batch in pinned host memory feeds the host-fed leg
+            hp = cq.host_array(n * sw, np.uint32).reshape(n, sw) if keep_host else None
+            hl = cq.host_array(n, np.uint8) if keep_host else None
+            dp = torch.empty((n, sw), dtype=torch.int32, device="cuda")
+            dl = torch.empty(n, dtype=torch.uint8, device="cuda")
+            for c0 in range(0, n, GEN_CHUNK):
+                m = min(GEN_CHUNK, n - c0)
+                w.reads_into(ascii_buf, 1000 + 16 * rank + j, c0, m, rl)
+                offs = np.arange(m + 1, dtype=np.uint64) * np.uint64(rl)
+                pk, ln, skipped = cq.pack_reads(ascii_buf[:m * rl], offs, h, sw)
+                assert skipped == 0
+                if j == 0 and c0 == 0 and ns:
+                    sample_bases = ascii_buf[:min(ns, m) * rl].copy()
+                    ns = min(ns, m)
+                if keep_host:
+                    hp[c0:c0 + m] = pk
+                    hl[c0:c0 + m] = ln
+                dp[c0:c0 + m].copy_(torch.from_numpy(pk.view(np.int32)))
+                dl[c0:c0 + m].copy_(torch.from_numpy(ln))
+            h_packed.append(hp); h_lens.append(hl); d_packed.append(dp); d_lens.append(dl)
+        del ascii_buf
+        torch.cuda.synchronize()
+        t_reads = time.time() - t0
+
+        cw = ix.counter_words(G)
+        nleaf = nu + nd
+        ctr = torch.zeros(cw, dtype=torch.int64, device="cuda")
+        rcd = torch.zeros(max(nleaf, 1), dtype=torch.int32, device="cuda")
+        h_ctr = torch.zeros(cw, dtype=torch.int64).pin_memory()
+        h_rc = torch.zeros(max(nleaf, 1), dtype=torch.int32).pin_memory()
         stream = torch.cuda.current_stream().cuda_stream
+
+        # ---- N > 1: the product's own communicator (RCCL through the C ABI); torch.distributed only carries
+        #      the 128-byte id, the barriers and the max over ranks
+        comm, reduce_how = None, None
+        if world > 1:
+            if rehearsal:
+                reduce_how = "gloo (one-GPU rehearsal; not RCCL)"
+            else:
+                try:
+                    uid = [cq.comm_unique_id() if rank == 0 else None]
+                    tdist.broadcast_object_list(uid, src=0)
+                    comm = cq.Comm(ix, uid[0], rank, world)
+                    reduce_how = "cq_counts_allreduce (RCCL, libcammiq_hip.so)"
+                except Exception as e:   # keep the scaling run alive and say so in the record
+                    comm = None
+                    reduce_how = f"torch.distributed all_reduce (fallback: cq_comm failed: {e})"
+                    print(f"[bench rank {rank}] {reduce_how}", file=sys.stderr, flush=True)
+                flag = torch.tensor([1 if comm is not None else 0], device="cuda")
+                tdist.all_reduce(flag, op=tdist.ReduceOp.MIN)
+                if int(flag.item()) == 0 and comm is not None:   # all ranks take the same path
+                    comm.close()
+                    comm = None
+                    reduce_how = "torch.distributed all_reduce (fallback: cq_comm failed on another rank)"
+
         step_no = [0]
-        per_step = args.allreduce_every_step and world > 1
 
         def step():
-            b = (step_no[0] & 1) if per_step else 0
+            j = step_no[0] % nb
             step_no[0] += 1
-            if per_step:
-                if pending[b] is not None:
-                    for wk in pending[b]:
-                        wk.wait()             # the collective that last used this buffer pair
-                    pending[b] = None
-                ctrs[b].zero_()               # resetCounters (query.cpp:1820-1840)
-                rcs[b].zero_()
-            ix.query_device(cq.MODE_P, d_packed.data_ptr(), d_lens.data_ptr(), n, sw, args.read_len, G,
-                            ctrs[b].data_ptr(), rcs[b].data_ptr(), stream)   # accumulates
-            if per_step:
-                pending[b] = cqdist.allreduce_counts(ctrs[b], rcs[b], async_op=True)
-            return b
+            ix.query_device(cq.MODE_P, d_packed[j].data_ptr(), d_lens[j].data_ptr(), n, sw, rl, G,
+                            ctr.data_ptr(), rcd.data_ptr(), stream)   # accumulates
+            h_ctr.copy_(ctr, non_blocking=True)                        # D2H of the counter block, per batch
 
         def finish_query():
-            """End of a query: the one exchange step (N > 1, unless every step already had its own)."""
-            if world > 1 and not per_step:
-                cqdist.allreduce_counts(ctrs[0], rcs[0])
+            """End of a query: the exchange step (N > 1), then everything the host hands on comes back."""
+            if world > 1:
+                if comm is not None:
+                    comm.allreduce_counts(ctr.data_ptr(), cw, rcd.data_ptr() if nleaf else None, nleaf, stream)
+                else:
+                    cqdist.allreduce_counts(ctr, rcd if nleaf else None)
+            h_ctr.copy_(ctr, non_blocking=True)
+            h_rc.copy_(rcd, non_blocking=True)                         # rcount once per query (pinned: link speed)
 
         def fence():
-            for b in (0, 1):
-                if pending[b] is not None:
-                    for wk in pending[b]:
-                        wk.wait()
-                    pending[b] = None
             if world > 1:
                 tdist.barrier()
             torch.cuda.synchronize()
@@ -172,16 +241,16 @@ def main():
             step()
         finish_query()                        # also warms RCCL up
         fence()
-        for b in (0, 1):                      # resetCounters before the timed query
-            ctrs[b].zero_()
-            rcs[b].zero_()
+        ctr.zero_()                           # resetCounters before the timed query
+        rcd.zero_()
+        step_no[0] = 0
         fence()
-        kms = []
-        last = 0
+        kms, kslow = [], []
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            last = step()
-            kms.append(ix.last_kernel_ms())   # HIP events on the launch stream, recorded inside the library
+            step()
+            a, b = ix.last_kernel_times()     # HIP events on the launch stream, recorded inside the library
+            kms.append(a); kslow.append(b)
         finish_query()
         fence()
         dt = time.perf_counter() - t0
@@ -189,83 +258,130 @@ def main():
             tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
             tdist.all_reduce(tmax, op=tdist.ReduceOp.MAX)
             dt = float(tmax.item())
-        ctr = ctrs[last]
-        counted_steps = 1 if per_step else args.steps   # how many batches the final counters hold
 
-        # ---- sanity on the last step's counters: every read lands in exactly one outcome
-        c = ctr.cpu().numpy().astype(np.uint64)
+        # ---- sanity on the query's counters: every read lands in exactly one outcome
+        c = h_ctr.numpy().astype(np.uint64)
         tot_reads = n * world
-        held_reads = tot_reads * counted_steps
-        nundet, nconf, nskip, nslow = (int(c[2 * (G + 1) + i]) for i in (0, 1, 2, 4))
-        cnt_u_sum = int(c[:G + 1].sum())
-        if not args.both and not os.environ.get("CAMMIQ_LIB"):
+        held_reads = tot_reads * args.steps
+        nundet, nconf, nskip, nflag, nslow = (int(c[2 * (G + 1) + i]) for i in (0, 1, 2, 3, 4))
+        cnt_u_sum, cnt_d_sum = int(c[:G + 1].sum()), int(c[G + 1:2 * G + 2].sum())
+        rc_sum = int(h_rc.numpy().view(np.uint32).astype(np.uint64).sum()) if nleaf else 0
+        assert nskip == 0 and nflag == 0
+        if not both and not os.environ.get("CAMMIQ_LIB"):
             assert cnt_u_sum + nundet + nconf + nskip == held_reads, "conservation of reads violated"
+        assert rc_sum >= max(cnt_u_sum, cnt_d_sum // 2) or os.environ.get("CAMMIQ_LIB"), "rcount did not come back"
 
         result = None
         if rank == 0:
             value = tot_reads * args.steps / dt / 1e6
-            B = algorithmic_bytes_per_read(args.read_len, h, tables)
             k_ms = float(np.mean(kms))
+            k_slow_ms = float(np.mean(kslow))
+            # Algorithmic bytes per read, SURVEY.md 8(d): ceil(rl/4) + 2 W T 16 -- one 16-byte slot (8-byte key,
+            # 8-byte payload) per window, strand and table.  The merged table keeps val_u and val_d in ONE 16-byte
+            # slot, so a --both probe touches the same 16 bytes as a --unique probe: the figure this design has to
+            # move per read is the T = 1 one for either index; the T = 2 contract figure is given beside it.
+            B = algorithmic_bytes_per_read(rl, h, 1)
+            B_contract = algorithmic_bytes_per_read(rl, h, tables)
             achieved = n * B / (k_ms * 1e-3) / 1e9
-            traffic = None
-            tp = os.path.join(ROOT, "profiles", "traffic.json")
-            default_workload = (G == 500 and n == 10_000_000 and args.read_len == 100 and not args.both
-                                and args.genome_len == 3_450_000)
-            if default_workload and os.path.exists(tp):   # the PMC passes were made on exactly this workload
+            roof = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                    "kernel": "classify_kernel<8,16,false>", "kernel_ms": round(k_ms, 4),
+                    "slow_path_kernel_ms": round(k_slow_ms, 4),
+                    "algorithmic_bytes_per_read": B,
+                    "algorithmic_note": "ceil(rl/4) + 2*(rl-h+1)*16: one 16-B slot per window and strand; the merged "
+                                        "u+d table answers both tables from that one slot",
+                    "contract_T_tables_bytes_per_read": B_contract,
+                    "contract_T_tables_GBs": round(n * B_contract / (k_ms * 1e-3) / 1e9, 2)}
+            # measured HBM traffic + gather ceiling of this exact workload, from the committed PMC passes
+            tp = os.path.join(ROOT, "profiles", "traffic_r02.json")
+            key = workload_key(G, args.genome_len, both, n, rl)
+            if os.path.exists(tp):
                 try:
-                    traffic = json.load(open(tp)).get("hbm_bytes_per_launch")
+                    ent = json.load(open(tp)).get(key)
                 except Exception:
-                    traffic = None
+                    ent = None
+                if ent:
+                    hb = float(ent["hbm_bytes_per_launch"])
+                    roof["traffic"] = hb
+                    roof["physical_GBs"] = round(hb / (k_ms * 1e-3) / 1e9, 2)
+                    roof["physical_frac"] = round(hb / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
+                    if ent.get("gather_ceiling_lines_per_s"):
+                        lines = hb / 64.0 / (k_ms * 1e-3)
+                        roof["gather_ceiling_frac"] = round(lines / float(ent["gather_ceiling_lines_per_s"]), 5)
+                        roof["gather_ceiling_note"] = ent.get("gather_ceiling_note")
             result = {
                 "metric": METRIC, "value": round(value, 3), "unit": "Mreads/s", "n_gpus": world,
                 "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64",
                 "data": "synthetic",
-                "config": {"workload": ("configs[2]-shape: " if args.both else "configs[1]: ") +
-                           f"{G} synthetic genomes x {args.genome_len} bp, "
-                           f"{'--both' if args.both else '--unique'} index h=k=26 ({nu}+{nd} leaves), "
-                           f"{n} x {args.read_len} bp reads per GPU per step (1% subst. errors, 10% off-database)",
-                           "reads_per_gpu": n, "read_len": args.read_len, "hash_len": h, "n_genomes": G,
+                "config": {"workload": f"{label}: {G} synthetic genomes x {args.genome_len} bp, "
+                           f"{'--both' if both else '--unique'} index h=k=26 ({nu}+{nd} leaves), "
+                           f"{n} x {rl} bp reads per GPU per step (1% subst. errors, 10% off-database), "
+                           f"{nb} distinct HBM-resident batches rotated",
+                           "workload_key": key,
+                           "reads_per_gpu": n, "read_len": rl, "hash_len": h, "n_genomes": G,
                            "leaves_u": nu, "leaves_d": nd, "table_GB": round(info["n_table_buckets"] * 64 / 1e9, 3),
                            "index_device_GB": round(info["device_bytes"] / 1e9, 3),
                            "table_buckets_overflowed": info["n_overflowed"], "table_max_chain": info["max_chain"],
-                           "parallelism": f"reads sharded x{world}, index replicated" +
-                                          ((", RCCL all-reduce of counts + rcount per step, overlapped with the next step's kernel"
-                                            if per_step else
-                                            ", one RCCL all-reduce of counts + rcount at the end of the query, inside the timed bracket")
-                                           if world > 1 else "")},
-                "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                             "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                             "kernel": "classify_kernel<8,16,false>", "kernel_ms": round(k_ms, 4),
-                             "algorithmic_bytes_per_read": B},
-                "kernel_Mreads_s": round(n / (k_ms * 1e-3) / 1e6, 3),
+                           "bracket": "K x (classify kernels + D2H of the counter block)"
+                                      + (", RCCL all-reduce of counts + rcount" if world > 1 else "")
+                                      + ", D2H of rcount (pinned) once; inputs resident in HBM",
+                           "parallelism": f"reads sharded x{world}, index replicated"
+                                          + (f"; exchange step: {reduce_how}" if world > 1 else "")},
+                "roofline": roof,
+                "kernel_Mreads_s": round(n / ((k_ms + k_slow_ms) * 1e-3) / 1e6, 3),
                 "outcome": {"reads": held_reads, "nundet": nundet, "nconf": nconf, "nskipped": nskip,
-                            "slow_path_reads": nslow, "cnt_u_sum": cnt_u_sum},
-                "setup_s": {"generate": round(t_gen, 2), "index_load_layout_upload": round(t_load, 2),
-                            "pack_reads": round(t_pack, 2)},
+                            "slow_path_reads": nslow, "cnt_u_sum": cnt_u_sum, "cnt_d_sum": cnt_d_sum, "rcount_sum": rc_sum},
+                "setup_s": {"generate_index": round(t_gen, 2), "index_load_layout_upload": round(t_load, 2),
+                            "generate_pack_upload_reads": round(t_reads, 2)},
             }
 
-        # ---- PCIe-inclusive rate of the host-buffer API (never `value`): ASCII reads in host
-        #      memory -> pack -> H2D -> kernel -> D2H, chunks pipelined inside cq_query
-        if rank == 0 and world == 1 and args.host_api:
-            ix.query(bases[:args.read_len * 1000], offs[:1001], G)          # warm the staging buffers
+        # ---- PCIe-inclusive rate (never `value`): SURVEY.md 8(d)'s bracket on the same batch -- packed reads in
+        #      pinned host memory -> pipelined H2D -> kernels -> D2H of counters and rcount (cq_query_packed)
+        if rank == 0 and host_fed:
+            out = ix.counts_out(G, pinned=True)
+            ix.query_packed(h_packed[0][:1 << 16], h_lens[0][:1 << 16], rl, G, out=out)     # warm the staging buffers
+            ts = []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                hq = ix.query_packed(h_packed[0], h_lens[0], rl, G, out=out)
+                ts.append(time.perf_counter() - t0)
+            th = min(ts)
+            row_bytes = sw * 4 + 1
+            result["host_fed"] = {
+                "Mreads_s": round(n / th / 1e6, 2), "ms": round(th * 1e3, 3), "runs_ms": [round(x * 1e3, 3) for x in ts],
+                "h2d_GBs": round(n * row_bytes / th / 1e9, 2), "bytes_per_read_on_the_wire": row_bytes,
+                "what": "cq_query_packed: packed reads in pinned host memory -> H2D in 2 M-read chunks on a copy stream, "
+                        "overlapped with the classify kernels -> D2H of the counter block and of rcount into pinned "
+                        "memory (SURVEY 8(d) bracket, = the reference's Time-for-query bracket); best of 3"}
+            # one query of batch 0 alone must agree with itself through both doors
+            ctr.zero_(); rcd.zero_()
+            ix.query_device(cq.MODE_P, d_packed[0].data_ptr(), d_lens[0].data_ptr(), n, sw, rl, G, ctr.data_ptr(),
+                            rcd.data_ptr(), stream)
+            torch.cuda.synchronize()
+            c0 = ctr.cpu().numpy().astype(np.uint64)
+            assert np.array_equal(c0[:G + 1], hq["cnt_u"]) and np.array_equal(c0[G + 1:2 * G + 2], hq["cnt_d"]), \
+                "host-fed path disagrees with the device path"
+            assert int(c0[2 * G + 2]) == hq["nundet"] and int(c0[2 * G + 3]) == hq["nconf"]
+            if nleaf:
+                assert np.array_equal(rcd.cpu().numpy().view(np.uint32)[:nu], hq["rcount_u"])
+
+        if rank == 0 and world == 1 and args.ascii_api and sample_bases is not None:
+            so = np.arange(ns + 1, dtype=np.uint64) * np.uint64(rl)
+            ix.query(sample_bases[:rl * 1000], so[:1001], G)
             t0 = time.perf_counter()
-            hq = ix.query(bases, offs, G)
+            ix.query(sample_bases, so, G)
             th = time.perf_counter() - t0
-            result["host_api"] = {"Mreads_s": round(n / th / 1e6, 2), "seconds": round(th, 4),
-                                  "what": "cq_query on ASCII reads in pageable host memory, counters back on the host "
-                                          "(pack + H2D + kernel + D2H, 2 M-read chunks double-buffered)"}
-            assert int(hq["cnt_u"].sum()) * counted_steps == cnt_u_sum and hq["nundet"] * counted_steps == nundet, \
-                "host API disagrees with device API"
+            result["ascii_api"] = {"Mreads_s": round(ns / th / 1e6, 2), "reads": ns,
+                                   "what": "cq_query on ASCII reads in pageable host memory (pack + H2D + kernel + D2H)"}
 
         # ---- CPU baseline (rank 0, N = 1 only): the oracle, a restatement of query64mt_p
-        if rank == 0 and world == 1 and not args.no_cpu_baseline and args.cpu_sample > 0:
+        if rank == 0 and world == 1 and not args.no_cpu_baseline and ns > 0:
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             import oracle_lib
-            ns = min(args.cpu_sample, n)
             cores = min(os.cpu_count() or 1, 16)   # a one-GPU box's CPU share is 16 cores
             oi = oracle_lib.OracleIndex(pu, pd)
-            sb, so = bases[:ns * args.read_len], offs[:ns + 1]
+            sb, so = sample_bases, np.arange(ns + 1, dtype=np.uint64) * np.uint64(rl)
             t0 = time.perf_counter()
             ref = oi.query(sb, so, G, mode=0, nthreads=cores)
             tc = time.perf_counter() - t0
@@ -275,7 +391,7 @@ def main():
             assert all(np.array_equal(fair[kk], ref[kk]) for kk in ("cnt_u", "cnt_d", "rcount_u", "rcount_d"))
             t0 = time.perf_counter()
             ns1 = max(ns // 8, 1)
-            oi.query(bases[:ns1 * args.read_len], offs[:ns1 + 1], G, mode=0, nthreads=1)
+            oi.query(sb[:ns1 * rl], so[:ns1 + 1], G, mode=0, nthreads=1)
             tc1 = time.perf_counter() - t0
             # parity gate on the very same sample, through the product's host API
             got = ix.query(sb, so, G)
@@ -285,7 +401,7 @@ def main():
                 raise SystemExit("PARITY FAILURE: GPU counters differ from the CPU oracle on the bench sample")
             result["cpu_baseline"] = {
                 "value": round(ns / tc / 1e6, 4), "unit": "Mreads/s", "cores": cores, "kind": "port",
-                "sample": f"first {ns} reads of the same batch, same index; OpenMP over reads with one global "
+                "sample": f"first {ns} reads of batch 0, same index; OpenMP over reads with one global "
                           f"critical section per update as query64mt_p (oracle/cammiq_oracle.c); "
                           f"same sample with atomic counter updates instead of the lock ('fair' variant): "
                           f"{ns / tf / 1e6:.4f} Mreads/s; single-thread rate on {ns1} reads: {ns1 / tc1 / 1e6:.4f} Mreads/s",
@@ -293,6 +409,8 @@ def main():
             result["parity_checked_reads"] = ns
         if rank == 0:
             print(json.dumps(result), flush=True)
+        if comm is not None:
+            comm.close()
     finally:
         if world > 1:
             tdist.barrier()

@@ -4,5 +4,5 @@ The product is ``libcammiq_hip.so`` (C ABI in ``include/cammiq_hip.h``, sources 
 ``cammiq_amd/csrc``) and the ``cammiq`` command-line shell built on it.  This package is
 the thin Python binding used by tests and bench.py, plus synthetic-input helpers.
 """
-from .binding import (CammiqError, Index, MODE_P, MODE_SC, lib, lib_path, pack_reads,  # noqa: F401
-                      stride_words)
+from .binding import (CammiqError, Comm, Index, MODE_P, MODE_SC, Multi, comm_unique_id,  # noqa: F401
+                      host_array, lib, lib_path, pack_reads, shard_range, stride_words)

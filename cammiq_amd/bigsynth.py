@@ -28,6 +28,9 @@ def _lib():
         L.cqs_write_index.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.cqs_make_reads.restype = C.c_int
         L.cqs_make_reads.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_double, C.c_double, C.c_void_p]
+        L.cqs_make_reads_at.restype = C.c_int
+        L.cqs_make_reads_at.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_double, C.c_double,
+                                        C.c_void_p]
         _LIB = L
     return _LIB
 
@@ -56,6 +59,14 @@ class World:
         if rc != 0:
             raise ValueError("read length exceeds genome length")
         return bases, np.arange(n + 1, dtype=np.uint64) * np.uint64(length)
+
+    def reads_into(self, out: np.ndarray, seed: int, first: int, n: int, length: int = 100, err: float = 0.01,
+                   frac_random: float = 0.1):
+        """Reads first .. first+n-1 of stream `seed` into out[:n*length] (a reusable ASCII buffer)."""
+        assert out.dtype == np.uint8 and out.size >= n * length and out.flags.c_contiguous
+        rc = _lib().cqs_make_reads_at(self._h, seed, first, n, length, err, frac_random, out.ctypes.data_as(C.c_void_p))
+        if rc != 0:
+            raise ValueError("read length exceeds genome length")
 
     def close(self):
         if self._h:

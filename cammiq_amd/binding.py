@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import weakref
 
 import numpy as np
 
@@ -62,7 +63,28 @@ SIGNATURES = {
     "cq_pairs_fetch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,
                                  C.POINTER(C.c_uint64)]),
     "cq_last_kernel_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
+    "cq_last_kernel_times": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "cq_query_packed": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32,
+                                  C.c_uint32, C.c_uint32, C.POINTER(_Counts)]),
+    "cq_host_alloc": (C.c_int, [C.POINTER(C.c_void_p), C.c_size_t]),
+    "cq_host_free": (None, [C.c_void_p]),
+    "cq_pairs_reserve": (C.c_int, [C.c_void_p, C.c_uint64]),
+    "cq_shard_range": (C.c_int, [C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "cq_multi_load": (C.c_int, [C.c_char_p, C.c_char_p, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]),
+    "cq_multi_size": (C.c_int, [C.c_void_p]),
+    "cq_multi_index": (C.c_void_p, [C.c_void_p, C.c_int]),
+    "cq_multi_query": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32,
+                                 C.POINTER(_Counts)]),
+    "cq_multi_query_packed": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32,
+                                        C.c_uint32, C.c_uint32, C.POINTER(_Counts)]),
+    "cq_multi_free": (None, [C.c_void_p]),
+    "cq_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "cq_comm_init_rank": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "cq_comm_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "cq_counts_allreduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p]),
+    "cq_comm_free": (None, [C.c_void_p]),
 }
+COMM_ID_BYTES = 128
 
 
 def lib_path() -> str:
@@ -114,12 +136,62 @@ def pack_reads(bases: np.ndarray, offsets: np.ndarray, hash_len: int, sw: int | 
     return packed, lens, int(sk.value)
 
 
+def shard_range(n_reads: int, rank: int, world: int):
+    """[n*p/P, n*(p+1)/P) -- the library's own sharding rule (cq_shard_range)."""
+    lo, hi = C.c_uint64(0), C.c_uint64(0)
+    _check(lib().cq_shard_range(n_reads, rank, world, C.byref(lo), C.byref(hi)))
+    return int(lo.value), int(hi.value)
+
+
+def host_array(n: int, dtype) -> np.ndarray:
+    """numpy array in page-locked host memory (cq_host_alloc); released when the last view dies."""
+    dt = np.dtype(dtype)
+    p = C.c_void_p()
+    nbytes = max(int(n) * dt.itemsize, 1)
+    _check(lib().cq_host_alloc(C.byref(p), nbytes))
+    buf = (C.c_uint8 * nbytes).from_address(p.value)
+    weakref.finalize(buf, lib().cq_host_free, C.c_void_p(p.value))   # every view keeps `buf` alive through .base
+    return np.frombuffer(buf, dtype=dt, count=int(n))
+
+
+class _CountsOut:
+    """Caller-owned output arrays of one classify call (cq_counts)."""
+
+    def __init__(self, n_genomes, n_leaves, pair_cap, pinned=False):
+        mk = host_array if pinned else (lambda n, dt: np.zeros(n, dt))
+        self.cu = np.zeros(n_genomes + 1, np.uint64)
+        self.cd = np.zeros(n_genomes + 1, np.uint64)
+        self.ru = mk(n_leaves[0], np.uint32)
+        self.rd = mk(n_leaves[1], np.uint32)
+        self.pa = np.zeros(pair_cap, np.uint32)
+        self.pb = np.zeros(pair_cap, np.uint32)
+        self.pc = np.zeros(pair_cap, np.uint64)
+        c = _Counts()
+        c.cnt_u, c.cnt_d = _p(self.cu).value, _p(self.cd).value
+        c.rcount_u = _p(self.ru).value if self.ru.size else None
+        c.rcount_d = _p(self.rd).value if self.rd.size else None
+        c.pair_a, c.pair_b, c.pair_cnt, c.pair_cap = _p(self.pa).value, _p(self.pb).value, _p(self.pc).value, pair_cap
+        self.c = c
+
+    def result(self):
+        c = self.c
+        k = int(c.n_pairs)
+        return dict(cnt_u=self.cu, cnt_d=self.cd, rcount_u=np.asarray(self.ru), rcount_d=np.asarray(self.rd),
+                    nundet=int(c.nundet), nconf=int(c.nconf), nskipped=int(c.nskipped),
+                    pairs={(int(self.pa[i]), int(self.pb[i])): int(self.pc[i]) for i in range(k)})
+
+
 class Index:
     """Opaque index handle: replaces FqReader::ht_u / ht_d (query.hpp:57-58)."""
 
-    def __init__(self, path_u: str, path_d: str | None = None, device: int = 0):
-        h = C.c_void_p()
-        _check(lib().cq_index_load(path_u.encode(), path_d.encode() if path_d else None, device, C.byref(h)))
+    def __init__(self, path_u: str, path_d: str | None = None, device: int = 0, _borrowed=None):
+        if _borrowed is not None:
+            h = C.c_void_p(_borrowed)
+            self._owned = False
+        else:
+            h = C.c_void_p()
+            _check(lib().cq_index_load(path_u.encode(), path_d.encode() if path_d else None, device, C.byref(h)))
+            self._owned = True
         self._h = h
         info = _Info()
         _check(lib().cq_index_get_info(self._h, C.byref(info)))
@@ -154,23 +226,22 @@ class Index:
         bases = np.ascontiguousarray(bases, np.uint8)
         offsets = np.ascontiguousarray(offsets, np.uint64)
         n = len(offsets) - 1
-        cu = np.zeros(n_genomes + 1, np.uint64)
-        cd = np.zeros(n_genomes + 1, np.uint64)
-        ru = np.zeros(self.n_leaves[0], np.uint32)
-        rd = np.zeros(self.n_leaves[1], np.uint32)
-        pa = np.zeros(pair_cap, np.uint32)
-        pb = np.zeros(pair_cap, np.uint32)
-        pc = np.zeros(pair_cap, np.uint64)
-        c = _Counts()
-        c.cnt_u, c.cnt_d = _p(cu).value, _p(cd).value
-        c.rcount_u = _p(ru).value if ru.size else None
-        c.rcount_d = _p(rd).value if rd.size else None
-        c.pair_a, c.pair_b, c.pair_cnt, c.pair_cap = _p(pa).value, _p(pb).value, _p(pc).value, pair_cap
-        _check(lib().cq_query(self._h, mode, _p(bases), _p(offsets), n, n_genomes, C.byref(c)))
-        k = int(c.n_pairs)
-        return dict(cnt_u=cu, cnt_d=cd, rcount_u=ru, rcount_d=rd, nundet=int(c.nundet), nconf=int(c.nconf),
-                    nskipped=int(c.nskipped),
-                    pairs={(int(pa[i]), int(pb[i])): int(pc[i]) for i in range(k)})
+        o = _CountsOut(n_genomes, self.n_leaves, pair_cap)
+        _check(lib().cq_query(self._h, mode, _p(bases), _p(offsets), n, n_genomes, C.byref(o.c)))
+        return o.result()
+
+    def query_packed(self, packed: np.ndarray, lens: np.ndarray, max_len: int, n_genomes: int,
+                     mode: int = MODE_P, pair_cap: int = 1 << 16, out: "_CountsOut | None" = None):
+        """cq_query_packed: pre-packed host rows -> pipelined H2D + classify + D2H of the counters."""
+        assert packed.dtype == np.uint32 and packed.flags.c_contiguous and lens.dtype == np.uint8
+        o = out or _CountsOut(n_genomes, self.n_leaves, pair_cap)
+        _check(lib().cq_query_packed(self._h, mode, _p(packed), _p(lens), len(lens), packed.shape[1], max_len,
+                                     n_genomes, C.byref(o.c)))
+        return o.result()
+
+    def counts_out(self, n_genomes: int, pair_cap: int = 1 << 16, pinned: bool = True) -> "_CountsOut":
+        """Reusable output arrays (rcount in page-locked memory when pinned)."""
+        return _CountsOut(n_genomes, self.n_leaves, pair_cap, pinned=pinned)
 
     def counter_words(self, n_genomes: int) -> int:
         return int(lib().cq_counter_words(n_genomes))
@@ -190,6 +261,20 @@ class Index:
         _check(lib().cq_last_kernel_ms(self._h, C.byref(ms)))
         return float(ms.value)
 
+    def last_kernel_times(self):
+        """(main kernel ms, exact slow-path kernel ms) of the most recent launch."""
+        a, b = C.c_float(0), C.c_float(0)
+        _check(lib().cq_last_kernel_times(self._h, C.byref(a), C.byref(b)))
+        return float(a.value), float(b.value)
+
+    def pairs_reserve(self, n_slots: int):
+        _check(lib().cq_pairs_reserve(self._h, n_slots))
+
+    def count_pairs(self) -> int:
+        n = C.c_uint64(0)
+        _check(lib().cq_pairs_fetch(self._h, None, None, None, 0, C.byref(n)))
+        return int(n.value)
+
     def fetch_pairs(self, pair_cap: int = 1 << 16):
         pa = np.zeros(pair_cap, np.uint32)
         pb = np.zeros(pair_cap, np.uint32)
@@ -200,7 +285,85 @@ class Index:
 
     def close(self):
         if getattr(self, "_h", None):
-            lib().cq_index_free(self._h)
+            if self._owned:
+                lib().cq_index_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Multi:
+    """cq_multi: one process, one host thread per GPU inside the library, RCCL all-reduce of the counts."""
+
+    def __init__(self, path_u: str, path_d: str | None, devices):
+        devs = (C.c_int * len(devices))(*devices)
+        h = C.c_void_p()
+        _check(lib().cq_multi_load(path_u.encode(), path_d.encode() if path_d else None, devs, len(devices), C.byref(h)))
+        self._h = h
+        self.size = int(lib().cq_multi_size(h))
+        self.shards = [Index(None, _borrowed=lib().cq_multi_index(h, i)) for i in range(self.size)]
+        self.n_leaves = self.shards[0].n_leaves
+        self.hash_len = self.shards[0].hash_len
+
+    def query(self, bases, offsets, n_genomes, mode=MODE_P, pair_cap=1 << 16):
+        bases = np.ascontiguousarray(bases, np.uint8)
+        offsets = np.ascontiguousarray(offsets, np.uint64)
+        o = _CountsOut(n_genomes, self.n_leaves, pair_cap)
+        _check(lib().cq_multi_query(self._h, mode, _p(bases), _p(offsets), len(offsets) - 1, n_genomes, C.byref(o.c)))
+        return o.result()
+
+    def query_packed(self, packed, lens, max_len, n_genomes, mode=MODE_P, pair_cap=1 << 16, out=None):
+        assert packed.dtype == np.uint32 and packed.flags.c_contiguous and lens.dtype == np.uint8
+        o = out or _CountsOut(n_genomes, self.n_leaves, pair_cap)
+        _check(lib().cq_multi_query_packed(self._h, mode, _p(packed), _p(lens), len(lens), packed.shape[1], max_len,
+                                           n_genomes, C.byref(o.c)))
+        return o.result()
+
+    def close(self):
+        if getattr(self, "_h", None):
+            for s_ in self.shards:
+                s_._h = None
+            lib().cq_multi_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def comm_unique_id() -> bytes:
+    buf = (C.c_uint8 * COMM_ID_BYTES)()
+    _check(lib().cq_comm_unique_id(buf))
+    return bytes(buf)
+
+
+class Comm:
+    """cq_comm: this process's rank in the RCCL communicator of a one-process-per-GPU job."""
+
+    def __init__(self, index: Index, uid: bytes, rank: int, world: int):
+        assert len(uid) == COMM_ID_BYTES
+        h = C.c_void_p()
+        buf = (C.c_uint8 * COMM_ID_BYTES).from_buffer_copy(uid)
+        _check(lib().cq_comm_init_rank(index._h, buf, rank, world, C.byref(h)))
+        self._h = h
+        self.rank, self.world = rank, world
+
+    def allreduce_counts(self, d_counters_ptr: int, n_counter_words: int, d_rcount_ptr: int | None, n_rcount: int,
+                         stream_ptr: int | None = None):
+        """In-place sum over all ranks of the device counter block and rcount array; asynchronous on the stream."""
+        _check(lib().cq_counts_allreduce(self._h, C.c_void_p(d_counters_ptr), n_counter_words,
+                                         C.c_void_p(d_rcount_ptr) if d_rcount_ptr else None, n_rcount,
+                                         C.c_void_p(stream_ptr) if stream_ptr else None))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().cq_comm_free(self._h)
             self._h = None
 
     def __del__(self):

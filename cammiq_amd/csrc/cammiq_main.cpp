@@ -8,9 +8,12 @@
 // not a port of it.  Out of scope here, exactly as in BASELINE.json's north star:
 //   --build        index construction stays with the reference's own binary;
 //   the ILP        runILP_* needs CPLEX/Gurobi; with --dump_counts FILE this shell writes
-//                  everything the unmodified ILP consumes (per-genome counts, per-leaf rcount
-//                  in map_sp order) so a host with a solver can pick it up.
-// Extensions (not in the reference): --device N, --dump_counts FILE, --image_cache, missing .bin2 allowed.
+//                  what the unmodified ILP consumes besides the index itself (per genome: counts,
+//                  glength, nus, nds; per leaf with rcount > 0: its record and rcount; reads and
+//                  bases of the query) so a host with a solver can pick it up
+//                  (include/cammiq_glue.hpp is the in-process version of the same hand-off).
+// Extensions (not in the reference): --device N, --gpus N / --devices a,b,.. (shards the reads over
+// several GPUs, RCCL all-reduce of the counts), --dump_counts FILE, --image_cache, missing .bin2 allowed.
 #include <dirent.h>
 #include <fcntl.h>
 #include <sys/mman.h>
@@ -33,10 +36,19 @@
 #include <vector>
 
 #include "../../include/cammiq_hip.h"
+#include "../../include/cammiq_glue.hpp"
 
 namespace {
 
-struct Genome { uint32_t taxID; std::string name; };
+// Genome (query.hpp:13-25): the per-genome state the ILP reads
+struct Genome {
+    uint32_t taxID = 0;
+    std::string name;
+    uint64_t read_cnts_u = 0, read_cnts_d = 0;
+    uint32_t glength = 0, nus = 0, nds = 0;
+    Genome() {}
+    Genome(uint32_t t, const std::string &n) : taxID(t), name(n) {}
+};
 
 bool valid_file(const char *p) { struct stat st; return stat(p, &st) == 0; }
 
@@ -73,7 +85,7 @@ std::vector<Genome> load_map(const std::string &fn)
             size_t i = (size_t)atoi(id.c_str());
             if (i < g.size()) g[i].name += "/" + name;
         } else {
-            g.push_back(Genome{t, name});
+            g.push_back(Genome(t, name));
             taxids.insert(t);
         }
     }
@@ -213,8 +225,10 @@ void list_fastq(const std::string &dir, std::vector<std::string> &out)
 
 int main(int argc, char **argv)
 {
-    int mode = -1, id_mode = 0, t = 1, h = -1, h1 = -1, h2 = -1, device = 0;
+    int mode = -1, id_mode = 0, t = 1, h = -1, h1 = -1, h2 = -1, device = 0, gpus = 1;
+    if (const char *e = getenv("CAMMIQ_GPUS")) gpus = atoi(e);
     size_t min_rl = 0;
+    std::vector<int> dev_list;
     std::string fi1, fi2, fm, output = "CAMMiQ_output.txt", fq_dir, dump;
     std::vector<std::string> fq_names;
     float erate = 0.01f;
@@ -258,6 +272,13 @@ int main(int argc, char **argv)
             return 0;
         }
         if (v == "--device") { device = atoi(need(i, "Please specify the GPU ordinal.\n")); continue; }
+        if (v == "--gpus") { gpus = atoi(need(i, "Please specify the number of GPUs.\n")); continue; }
+        if (v == "--devices") {   // explicit ordinals, comma separated; always takes the multi-GPU path
+            std::istringstream ls(need(i, "Please specify the GPU ordinals.\n"));
+            std::string tok;
+            while (std::getline(ls, tok, ',')) if (!tok.empty()) dev_list.push_back(atoi(tok.c_str()));
+            continue;
+        }
         if (v == "--image_cache") { setenv("CAMMIQ_IMAGE_CACHE", "1", 1); continue; }   // see cq_cache.cpp
         if (v == "--dump_counts") { dump = need(i, "Please specify the counts file name.\n"); continue; }
         if (v == "-h") {
@@ -332,10 +353,25 @@ int main(int argc, char **argv)
     std::future<Reads> next_fq = parse_async(0);
 
     auto t0 = std::chrono::high_resolution_clock::now();
+    // one GPU: a plain handle; several: the library shards the reads over devices device .. device+gpus-1
+    // and all-reduces the counts over RCCL (cq_multi_*); the results are the same, bit for bit
     cq_index *ix = nullptr;
-    if (cq_index_load(fi1.c_str(), fi2.empty() ? nullptr : fi2.c_str(), device, &ix) != CQ_OK) {
-        fprintf(stderr, "%s\n", cq_last_error());
-        return EXIT_FAILURE;
+    cq_multi *mx = nullptr;
+    if (!dev_list.empty()) gpus = (int)dev_list.size();
+    if (gpus < 1 || gpus > 64) die("The number of GPUs should be in range [1, 64].\n");
+    if (gpus == 1 && dev_list.empty()) {
+        if (cq_index_load(fi1.c_str(), fi2.empty() ? nullptr : fi2.c_str(), device, &ix) != CQ_OK) {
+            fprintf(stderr, "%s\n", cq_last_error());
+            return EXIT_FAILURE;
+        }
+    } else {
+        std::vector<int> devs = dev_list;
+        if (devs.empty()) for (int d = 0; d < gpus; d++) devs.push_back(device + d);
+        if (cq_multi_load(fi1.c_str(), fi2.empty() ? nullptr : fi2.c_str(), devs.data(), gpus, &mx) != CQ_OK) {
+            fprintf(stderr, "%s\n", cq_last_error());
+            return EXIT_FAILURE;
+        }
+        ix = cq_multi_index(mx, 0);
     }
     cq_index_info info;
     cq_index_get_info(ix, &info);
@@ -354,6 +390,15 @@ int main(int argc, char **argv)
         leaves[tb].resize(info.n_leaves[tb]);
         cq_index_leaves(ix, tb, leaves[tb].data());
     }
+    // FqReader::loadGenomeLength (query.cpp:158-205): glength / nus / nds from the three text files next
+    // to index_u.  The reference calls it in every quantification query and in --read_cnts queries given
+    // with -q (query.cpp:245,283,347) but not in --read_cnts queries given with -Q (:303-331), and aborts
+    // when a file is missing.  Same here (exit instead of abort); only a --unique index (no .bin2) may
+    // lack unique_lmer_count_d.out, which such a build never writes (build.cpp:671-698).
+    if (id_mode == 0 || fq_dir.empty()) {
+        if (const char *msg = cq_glue::load_genome_meta(cq_glue::index_dir(fi1), genomes, fi2.empty())) die(msg);
+        fprintf(stderr, "Loaded genome length file.\n");
+    }
 
     std::vector<uint64_t> cu(G + 1), cd(G + 1), pc(1 << 16);
     std::vector<uint32_t> ru(info.n_leaves[0]), rd(info.n_leaves[1]), pa(1 << 16), pb(1 << 16);
@@ -365,11 +410,27 @@ int main(int argc, char **argv)
         fprintf(stderr, "Querying %s.\n", cur.c_str());
         auto q0 = std::chrono::high_resolution_clock::now();
         cq_counts c;
-        memset(&c, 0, sizeof c);
-        c.cnt_u = cu.data(); c.cnt_d = cd.data();
-        c.rcount_u = ru.empty() ? nullptr : ru.data(); c.rcount_d = rd.empty() ? nullptr : rd.data();
-        c.pair_a = pa.data(); c.pair_b = pb.data(); c.pair_cnt = pc.data(); c.pair_cap = pc.size();
-        int rc = cq_query(ix, id_mode ? CQ_MODE_SC : CQ_MODE_P, fq.bases.get(), fq.offs.get(), fq.n_reads, G, &c);
+        const int qmode = id_mode ? CQ_MODE_SC : CQ_MODE_P;
+        int rc;
+        for (;;) {
+            memset(&c, 0, sizeof c);
+            c.cnt_u = cu.data(); c.cnt_d = cd.data();
+            c.rcount_u = ru.empty() ? nullptr : ru.data(); c.rcount_d = rd.empty() ? nullptr : rd.data();
+            c.pair_a = pa.data(); c.pair_b = pb.data(); c.pair_cnt = pc.data(); c.pair_cap = pc.size();
+            rc = mx ? cq_multi_query(mx, qmode, fq.bases.get(), fq.offs.get(), fq.n_reads, G, &c)
+                    : cq_query(ix, qmode, fq.bases.get(), fq.offs.get(), fq.n_reads, G, &c);
+            if (rc == CQ_ERR_LIMIT && c.n_pairs > pc.size()) {   // read_cnts_b has more entries than the arrays: grow, ask again
+                pa.resize(c.n_pairs); pb.resize(c.n_pairs); pc.resize(c.n_pairs);
+                if (!mx) {   // the single-GPU library kept the pairs: fetch them, no second classify
+                    uint64_t np = 0;
+                    rc = cq_pairs_fetch(ix, pa.data(), pb.data(), pc.data(), pc.size(), &np);
+                    c.pair_a = pa.data(); c.pair_b = pb.data(); c.pair_cnt = pc.data(); c.n_pairs = np;
+                    break;
+                }
+                continue;
+            }
+            break;
+        }
         if (rc != CQ_OK) { fprintf(stderr, "%s\n", cq_last_error()); return EXIT_FAILURE; }
         fprintf(stderr, "Processed %lu reads.\r", (unsigned long)fq.n_reads);
         fprintf(stderr, "\nNumber of unlabeled reads: %lu.\n", (unsigned long)c.nundet);
@@ -391,25 +452,32 @@ int main(int argc, char **argv)
             fclose(fo);
         }
         if (!dump.empty()) {
-            // Everything runILP_* reads from FqReader state (query.cpp:1157-1226): per-genome
-            // counts, and per genome g the rcount of every leaf of map_sp[g] in decode order.
+            // What runILP_* reads from FqReader state besides the index (query.cpp:1083-1226): reads[f].size()
+            // and tlengths[f]; per genome read_cnts_u/_d, glength, nus, nds; per leaf its record and rcount --
+            // leaves with rcount 0 are not listed, the consumer has them from the index (cq_index_leaves,
+            // decode order = leaf index; map_sp[g] = the leaves naming g, in that order).
             FILE *fo = fopen(dump.c_str(), f == 0 ? "w" : "a");
             if (!fo) die("Can not open output file %s.\n", dump.c_str());
-            fprintf(fo, "#query\t%s\tnundet\t%lu\tnconf\t%lu\n", cur.c_str(), (unsigned long)c.nundet, (unsigned long)c.nconf);
+            if (f == 0) fprintf(fo, "#cammiq_counts\t2\n");
+            fprintf(fo, "#query\t%s\tn_reads\t%lu\ttotal_bases\t%lu\tnundet\t%lu\tnconf\t%lu\n", cur.c_str(),
+                    (unsigned long)fq.n_reads, (unsigned long)fq.n_bases, (unsigned long)c.nundet, (unsigned long)c.nconf);
             for (uint32_t g = 1; g <= G; g++)
-                fprintf(fo, "G\t%u\t%u\t%lu\t%lu\n", g, genomes[g].taxID, (unsigned long)cu[g], (unsigned long)cd[g]);
+                fprintf(fo, "G\t%u\t%u\t%lu\t%lu\t%u\t%u\t%u\n", g, genomes[g].taxID, (unsigned long)cu[g], (unsigned long)cd[g],
+                        genomes[g].glength, genomes[g].nus, genomes[g].nds);
             if (!id_mode)
                 for (int tb = 0; tb < 2; tb++)
                     for (size_t i = 0; i < leaves[tb].size(); i++) {
                         const uint32_t r = tb ? rd[i] : ru[i];
-                        if (r) fprintf(fo, "L\t%c\t%zu\t%u\t%u\t%u\t%u\n", tb ? 'd' : 'u', i, leaves[tb][i].refID1,
-                                       leaves[tb][i].refID2, (unsigned)leaves[tb][i].depth, r);
+                        const cq_leaf &lf = leaves[tb][i];
+                        if (r) fprintf(fo, "L\t%c\t%zu\t%u\t%u\t%u\t%u\t%u\t%u\n", tb ? 'd' : 'u', i, lf.refID1, lf.refID2,
+                                       (unsigned)lf.depth, (unsigned)lf.ucount1, (unsigned)lf.ucount2, r);
                     }
             for (uint64_t i = 0; i < c.n_pairs; i++)
                 fprintf(fo, "P\t%u\t%u\t%lu\n", pa[i], pb[i], (unsigned long)pc[i]);
             fclose(fo);
         }
     }
-    cq_index_free(ix);
+    if (mx) cq_multi_free(mx);
+    else cq_index_free(ix);
     return 0;
 }

@@ -4,8 +4,17 @@
 // (/root/reference/src/query.cpp:109-123) and FqReader::query64_p / query64mt_p / query64_sc
 // (query.cpp:458-1080): load + lay out + upload the index, then run the HIP classify
 // kernels on reads and hand the counters back.  No CPU classify path exists here.
+//
+// Multi-GPU (no reference analogue -- the reference's only parallel axis is the
+// OpenMP loop over reads, query.cpp:664-665): reads are sharded in contiguous ranges, the index is
+// replicated in every GPU's HBM, and the one exchange step is an RCCL all-reduce(sum) of the
+// counter block and of rcount at the end of a query, before the host hands the counts on
+// (query.cpp:251-258).  Two shapes: cq_multi_* (one process, one host thread per device,
+// ncclCommInitAll) and cq_comm_* (one process per GPU, ncclCommInitRank).
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
 #include <chrono>
+#include <map>
 #include <memory>
 
 #include <cstdarg>
@@ -39,41 +48,71 @@ int fail(int code, const std::string &msg)
                         std::string(#call) + ": " + hipGetErrorString(e_));                     \
     } while (0)
 
-constexpr uint32_t kPairCap = 1u << 20;
+#define CQ_NCCL(call)                                                                                       \
+    do {                                                                                                    \
+        ncclResult_t r_ = (call);                                                                           \
+        if (r_ != ncclSuccess) return fail(CQ_ERR_COMM, std::string(#call) + ": " + ncclGetErrorString(r_)); \
+    } while (0)
 
-}  // namespace
+constexpr uint32_t kPairCapDefault = 1u << 20;   // slots of the SC-mode pair map (grown on demand)
+constexpr uint64_t kChunk = 1ull << 21;          // reads per pipelined chunk of the host-fed paths
+constexpr size_t kBounce = 16u << 20;            // pinned bounce buffer for D2H into pageable arrays
 
-struct cq_index {
+// What decode + layout leave on the host.  One copy serves every handle of a cq_multi (the
+// index is replicated in HBM, not in host memory).
+struct HostIndex {
     cq::DecodedTable tab[2];
     cq::FlatImage img;
     uint64_t n_file_buckets[2] = {0, 0};
     uint64_t n_trie_nodes = 0;
     bool from_cache = false;
     uint32_t doubly_flag[2] = {0, 1};
+};
+
+}  // namespace
+
+struct cq_index {
+    std::shared_ptr<HostIndex> H;
     int device = CQ_DEVICE_NONE;
     int n_cus = 0;
     uint64_t device_bytes = 0;
     // device image
     void *d_slots = nullptr, *d_nodes = nullptr, *d_leaf_rids = nullptr;
     cq::DevIndex dev{};
-    // per-handle workspace (grown on demand, reused across calls)
+    // per-handle workspace (grown on demand, reused across calls): ONE query in flight per handle
     uint32_t *d_ovf_list = nullptr, *d_ovf_count = nullptr;
     uint64_t *d_stamps = nullptr;   // 8 words of their own for diagnostic (CQ_STAMPS) kernel builds
     uint64_t ovf_cap = 0;
     uint64_t *d_pair_keys = nullptr, *d_pair_cnts = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    uint32_t pair_cap = 0;          // slots, power of two
+    hipEvent_t ev0 = nullptr, ev_mid = nullptr, ev1 = nullptr;   // start | fast kernel done | slow kernel done
     bool ev_valid = false;
-    // host-buffer path (cq_query): two staging slots so that packing chunk c+1 on the CPU, its
-    // H2D copy and the classify kernel of chunk c overlap
+    // host-fed paths (cq_query, cq_query_packed): two staging slots so that packing chunk c+1 on
+    // the CPU, its H2D copy and the classify kernel of chunk c overlap
     struct Slot {
         uint32_t *h_packed = nullptr, *d_packed = nullptr;   // pinned host / device rows
         uint8_t *h_lens = nullptr, *d_lens = nullptr;
-        size_t cap_words = 0, cap_reads = 0;
+        size_t cap_words_h = 0, cap_reads_h = 0, cap_words_d = 0, cap_reads_d = 0;
         hipEvent_t copied = nullptr, done = nullptr;
     } slot[2];
     hipStream_t s_copy = nullptr, s_comp = nullptr;
     uint64_t *d_ctr = nullptr; size_t ctr_cap = 0;
     uint32_t *d_rc = nullptr; size_t rc_cap = 0;
+    void *h_bounce[2] = {nullptr, nullptr};
+    hipEvent_t ev_bounce[2] = {nullptr, nullptr};
+};
+
+// One RCCL communicator bound to one handle's device.
+struct cq_comm {
+    ncclComm_t comm = nullptr;
+    int device = 0, rank = 0, n_ranks = 1;
+};
+
+struct cq_multi {
+    std::vector<cq_index *> ix;        // one per entry of the device list
+    std::vector<int> leader_of;        // ix[i]'s device group: index of the first handle on that device
+    std::vector<int> leaders;          // handles that take part in the RCCL all-reduce (distinct devices)
+    std::vector<ncclComm_t> comms;     // one per leader, ncclCommInitAll
 };
 
 namespace {
@@ -102,8 +141,8 @@ void release_device(cq_index *ix)
     }
     if (ix->d_pair_keys) (void)hipFree(ix->d_pair_keys);
     if (ix->d_pair_cnts) (void)hipFree(ix->d_pair_cnts);
-    if (ix->ev0) (void)hipEventDestroy(ix->ev0);
-    if (ix->ev1) (void)hipEventDestroy(ix->ev1);
+    for (hipEvent_t e : {ix->ev0, ix->ev_mid, ix->ev1, ix->ev_bounce[0], ix->ev_bounce[1]})
+        if (e) (void)hipEventDestroy(e);
     for (auto &sl : ix->slot) {
         if (sl.h_packed) (void)hipHostFree(sl.h_packed);
         if (sl.h_lens) (void)hipHostFree(sl.h_lens);
@@ -112,12 +151,48 @@ void release_device(cq_index *ix)
         if (sl.copied) (void)hipEventDestroy(sl.copied);
         if (sl.done) (void)hipEventDestroy(sl.done);
     }
+    for (void *b : ix->h_bounce) if (b) (void)hipHostFree(b);
     if (ix->s_copy) (void)hipStreamDestroy(ix->s_copy);
     if (ix->s_comp) (void)hipStreamDestroy(ix->s_comp);
     if (ix->d_ctr) (void)hipFree(ix->d_ctr);
     if (ix->d_rc) (void)hipFree(ix->d_rc);
 }
 
+// (Re)allocate the SC-mode pair map with `slots` slots (power of two), empty.
+int pairs_alloc(cq_index *ix, uint32_t slots)
+{
+    if (ix->d_pair_keys) (void)hipFree(ix->d_pair_keys);
+    if (ix->d_pair_cnts) (void)hipFree(ix->d_pair_cnts);
+    ix->d_pair_keys = ix->d_pair_cnts = nullptr;
+    ix->pair_cap = 0;
+    CQ_HIP(hipMalloc((void **)&ix->d_pair_keys, (size_t)slots * 8));
+    CQ_HIP(hipMalloc((void **)&ix->d_pair_cnts, (size_t)slots * 8));
+    CQ_HIP(hipMemset(ix->d_pair_keys, 0xFF, (size_t)slots * 8));
+    CQ_HIP(hipMemset(ix->d_pair_cnts, 0, (size_t)slots * 8));
+    ix->pair_cap = slots;
+    return CQ_OK;
+}
+
+int pairs_clear(cq_index *ix)
+{
+    CQ_HIP(hipMemset(ix->d_pair_keys, 0xFF, (size_t)ix->pair_cap * 8));
+    CQ_HIP(hipMemset(ix->d_pair_cnts, 0, (size_t)ix->pair_cap * 8));
+    return CQ_OK;
+}
+
+uint32_t pair_cap_from_env()
+{
+    // test knob: start the SC pair map small so that its growth path runs on small inputs
+    if (const char *v = getenv("CAMMIQ_PAIR_SLOTS")) {
+        uint32_t s = 16;
+        const unsigned long want = strtoul(v, nullptr, 10);
+        while (s < want && s < (1u << 30)) s <<= 1;
+        return s;
+    }
+    return kPairCapDefault;
+}
+
+// Copy the flat image into the HBM of ix->device.
 int upload(cq_index *ix)
 {
     int ndev = 0;
@@ -128,7 +203,7 @@ int upload(cq_index *ix)
     hipDeviceProp_t prop;
     CQ_HIP(hipGetDeviceProperties(&prop, ix->device));
     ix->n_cus = prop.multiProcessorCount;
-    const cq::FlatImage &img = ix->img;
+    const cq::FlatImage &img = ix->H->img;
     const size_t sb = img.table_words * sizeof(uint32_t);
     const size_t nb = img.nodes.size() * sizeof(cq::Node);
     const size_t nl = img.leaf_r1.size();
@@ -151,13 +226,12 @@ int upload(cq_index *ix)
     CQ_HIP(hipMalloc((void **)&ix->d_ovf_count, sizeof(uint32_t)));
     CQ_HIP(hipMalloc((void **)&ix->d_stamps, 8 * sizeof(uint64_t)));
     CQ_HIP(hipMemset(ix->d_stamps, 0, 8 * sizeof(uint64_t)));
-    CQ_HIP(hipMalloc((void **)&ix->d_pair_keys, (size_t)kPairCap * 8));
-    CQ_HIP(hipMalloc((void **)&ix->d_pair_cnts, (size_t)kPairCap * 8));
-    CQ_HIP(hipMemset(ix->d_pair_keys, 0xFF, (size_t)kPairCap * 8));
-    CQ_HIP(hipMemset(ix->d_pair_cnts, 0, (size_t)kPairCap * 8));
+    int rc = pairs_alloc(ix, pair_cap_from_env());
+    if (rc != CQ_OK) return rc;
     CQ_HIP(hipEventCreate(&ix->ev0));
+    CQ_HIP(hipEventCreate(&ix->ev_mid));
     CQ_HIP(hipEventCreate(&ix->ev1));
-    ix->device_bytes = sb + nb + nl * sizeof(uint2) + (size_t)kPairCap * 16;
+    ix->device_bytes = sb + nb + nl * sizeof(uint2) + (size_t)ix->pair_cap * 16;
     ix->dev.slots = (const uint4 *)ix->d_slots;
     ix->dev.nodes = (const uint4 *)ix->d_nodes;
     ix->dev.leaf_rids = (const uint2 *)ix->d_leaf_rids;
@@ -166,8 +240,6 @@ int upload(cq_index *ix)
     ix->dev.minimizer_len = cq_minimizer_len(img.hash_len);
     return CQ_OK;
 }
-
-}  // namespace
 
 // CAMMIQ_LOAD_TIMING=1: stage timings of cq_index_load on stderr (diagnostic)
 struct LoadTimer {
@@ -181,6 +253,87 @@ struct LoadTimer {
     }
 };
 
+// Decode + lay out (or read the image cache): everything of cq_index_load that happens on the
+// host.  budget = bytes of HBM the table may take (1e30 = unlimited).
+int prepare_host(const char *path_u, const char *path_d, double budget, std::shared_ptr<HostIndex> &out, LoadTimer &lt)
+{
+    std::shared_ptr<HostIndex> H(new (std::nothrow) HostIndex());
+    if (!H) return fail(CQ_ERR_NOMEM, "out of memory");
+    const bool have_d = path_d && path_d[0];
+    // Optional image cache next to index_u (cq_cache.cpp); the .bin files stay authoritative.
+    const char *ce = getenv("CAMMIQ_IMAGE_CACHE");
+    const bool use_cache = ce && ce[0] == '1';
+    const std::string cache_file = std::string(path_u) + ".cqimg";
+    cq::SourceStamp stamp;
+    const bool stamped = use_cache && cq::stamp_sources(path_u, have_d ? path_d : "", stamp);
+    bool from_cache = false;
+    const double kpb_override = getenv("CAMMIQ_KEYS_PER_BUCKET") ? atof(getenv("CAMMIQ_KEYS_PER_BUCKET")) : 0.0;
+    if (stamped)
+        from_cache = cq::load_image(cache_file, stamp, kpb_override, budget >= 1e29 ? ~0ull : (uint64_t)budget, H->tab, H->img);
+    if (from_cache) lt.lap("image cache read");
+    // The reference loads the two files on two pthreads (query.cpp:112-116); same here.
+    int rc_u = CQ_OK, rc_d = CQ_OK;
+    std::string err_u, err_d;
+    if (!from_cache) try {
+        std::thread td;
+        if (have_d) td = std::thread([&] { rc_d = cq::decode_table(path_d, H->tab[1], err_d); });
+        rc_u = cq::decode_table(path_u, H->tab[0], err_u);
+        if (have_d) td.join();
+        if (rc_u != CQ_OK) return fail(rc_u, err_u);
+        if (rc_d != CQ_OK) return fail(rc_d, err_d);
+        if (!have_d) cq::make_empty_table(H->tab[0].hash_len, H->tab[1]);
+        lt.lap("decode");
+        std::string err;
+        // Average keys per 4-slot bucket of the device table.  Emptier tables overflow less
+        // (fewer windows take the exact path): 1.0 costs 64 B of HBM per key (measured: 0.5 -> +2 %,
+        // 1.5 -> -3 %); when the table would not fit comfortably it is packed tighter.
+        // CAMMIQ_KEYS_PER_BUCKET overrides (tuning knob, not part of the ABI).
+        double kpb = 1.0;
+        const double keys = (double)(H->tab[0].bucket_key.size() + H->tab[1].bucket_key.size());
+        if (keys / kpb * 64.0 > budget) kpb = std::min(3.2, keys * 64.0 / budget);
+        if (kpb_override > 0.0) kpb = kpb_override;
+        int rc = cq::build_image(H->tab[0], H->tab[1], kpb, H->img, err);
+        if (rc != CQ_OK) return fail(rc, err);
+        lt.lap("layout");
+        // bucket/node arrays of the decode stage are no longer needed; leaves are (cq_index_leaves)
+        for (int t = 0; t < 2; t++) {
+            std::vector<uint64_t>().swap(H->tab[t].bucket_key);
+            std::vector<uint32_t>().swap(H->tab[t].bucket_code);
+            std::vector<cq::Node>().swap(H->tab[t].nodes);
+        }
+        if (stamped) { (void)cq::save_image(cache_file, stamp, kpb_override, H->tab, H->img); lt.lap("image cache write"); }
+    } catch (const std::bad_alloc &) {
+        return fail(CQ_ERR_NOMEM, "out of memory while loading the index");
+    }
+    for (int t = 0; t < 2; t++) {
+        H->n_file_buckets[t] = H->tab[t].n_file_buckets;
+        H->doubly_flag[t] = H->tab[t].doubly;
+    }
+    H->from_cache = from_cache;
+    H->n_trie_nodes = H->img.nodes.size() - 1;
+    out = H;
+    return CQ_OK;
+}
+
+// The image now lives in HBM: drop the host copy (cq_index_probe needs a CQ_DEVICE_NONE handle).
+void drop_host_image(HostIndex &H)
+{
+    H.img.table.reset();
+    std::vector<cq::Node>().swap(H.img.nodes);
+    std::vector<uint32_t>().swap(H.img.leaf_r1);
+    std::vector<uint32_t>().swap(H.img.leaf_r2);
+}
+
+double table_budget(int device)
+{
+    size_t free_b = 0, total_b = 0;
+    if (hipSetDevice(device) == hipSuccess && hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b)
+        return 0.5 * (double)free_b;   // at most half of what is free
+    return 1e30;
+}
+
+}  // namespace
+
 extern "C" {
 
 int cq_abi_version(void) { return CQ_ABI_VERSION; }
@@ -193,77 +346,15 @@ int cq_index_load(const char *path_u, const char *path_d, int device, cq_index *
     *out = nullptr;
     cq_index *ix = new (std::nothrow) cq_index();
     if (!ix) return fail(CQ_ERR_NOMEM, "out of memory");
-    const bool have_d = path_d && path_d[0];
-    // device-memory budget for the table: at most half of what is free
-    double budget = 1e30;
-    if (device >= 0) {
-        size_t free_b = 0, total_b = 0;
-        if (hipSetDevice(device) == hipSuccess && hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b)
-            budget = 0.5 * (double)free_b;
-    }
-    // Optional image cache next to index_u (cq_cache.cpp); the .bin files stay authoritative.
-    const char *ce = getenv("CAMMIQ_IMAGE_CACHE");
-    const bool use_cache = ce && ce[0] == '1';
-    const std::string cache_file = std::string(path_u) + ".cqimg";
-    cq::SourceStamp stamp;
-    const bool stamped = use_cache && cq::stamp_sources(path_u, have_d ? path_d : "", stamp);
-    bool from_cache = false;
     LoadTimer lt;
-    const double kpb_override = getenv("CAMMIQ_KEYS_PER_BUCKET") ? atof(getenv("CAMMIQ_KEYS_PER_BUCKET")) : 0.0;
-    if (stamped)
-        from_cache = cq::load_image(cache_file, stamp, kpb_override, budget >= 1e29 ? ~0ull : (uint64_t)budget, ix->tab, ix->img);
-    if (from_cache) lt.lap("image cache read");
-    // The reference loads the two files on two pthreads (query.cpp:112-116); same here.
-    int rc_u = CQ_OK, rc_d = CQ_OK;
-    std::string err_u, err_d;
-    if (!from_cache) try {
-        std::thread td;
-        if (have_d) td = std::thread([&] { rc_d = cq::decode_table(path_d, ix->tab[1], err_d); });
-        rc_u = cq::decode_table(path_u, ix->tab[0], err_u);
-        if (have_d) td.join();
-        if (rc_u != CQ_OK) { delete ix; return fail(rc_u, err_u); }
-        if (rc_d != CQ_OK) { delete ix; return fail(rc_d, err_d); }
-        if (!have_d) cq::make_empty_table(ix->tab[0].hash_len, ix->tab[1]);
-        lt.lap("decode");
-        std::string err;
-        // Average keys per 4-slot bucket of the device table.  Emptier tables overflow less
-        // (fewer windows take the exact path): 1.0 costs 64 B of HBM per key (measured: 0.5 -> +2 %,
-        // 1.5 -> -3 %); when the table would not fit comfortably it is packed tighter.
-        // CAMMIQ_KEYS_PER_BUCKET overrides (tuning knob, not part of the ABI).
-        double kpb = 1.0;
-        const double keys = (double)(ix->tab[0].bucket_key.size() + ix->tab[1].bucket_key.size());
-        if (keys / kpb * 64.0 > budget) kpb = std::min(3.2, keys * 64.0 / budget);
-        if (kpb_override > 0.0) kpb = kpb_override;
-        int rc = cq::build_image(ix->tab[0], ix->tab[1], kpb, ix->img, err);
-        if (rc != CQ_OK) { delete ix; return fail(rc, err); }
-        lt.lap("layout");
-        // bucket/node arrays of the decode stage are no longer needed; leaves are (cq_index_leaves)
-        for (int t = 0; t < 2; t++) {
-            std::vector<uint64_t>().swap(ix->tab[t].bucket_key);
-            std::vector<uint32_t>().swap(ix->tab[t].bucket_code);
-            std::vector<cq::Node>().swap(ix->tab[t].nodes);
-        }
-        if (stamped) { (void)cq::save_image(cache_file, stamp, kpb_override, ix->tab, ix->img); lt.lap("image cache write"); }
-    } catch (const std::bad_alloc &) {
-        delete ix;
-        return fail(CQ_ERR_NOMEM, "out of memory while loading the index");
-    }
-    for (int t = 0; t < 2; t++) {
-        ix->n_file_buckets[t] = ix->tab[t].n_file_buckets;
-        ix->doubly_flag[t] = ix->tab[t].doubly;
-    }
-    ix->from_cache = from_cache;
+    int rc = prepare_host(path_u, path_d, device >= 0 ? table_budget(device) : 1e30, ix->H, lt);
+    if (rc != CQ_OK) { delete ix; return rc; }
     ix->device = device;
     if (device >= 0) {
-        int rc = upload(ix);
+        rc = upload(ix);
         lt.lap("upload");
         if (rc != CQ_OK) { release_device(ix); delete ix; return rc; }
-        // the image now lives in HBM: drop the host copy (cq_index_probe needs a CQ_DEVICE_NONE handle)
-        ix->n_trie_nodes = ix->img.nodes.size() - 1;
-        ix->img.table.reset();
-        std::vector<cq::Node>().swap(ix->img.nodes);
-        std::vector<uint32_t>().swap(ix->img.leaf_r1);
-        std::vector<uint32_t>().swap(ix->img.leaf_r2);
+        drop_host_image(*ix->H);
     }
     *out = ix;
     return CQ_OK;
@@ -273,29 +364,30 @@ int cq_index_get_info(const cq_index *ix, cq_index_info *info)
 {
     if (!ix || !info) return fail(CQ_ERR_ARG, "cq_index_get_info: NULL argument");
     memset(info, 0, sizeof *info);
+    const HostIndex &H = *ix->H;
     info->abi_version = CQ_ABI_VERSION;
-    info->hash_len = ix->img.hash_len;
-    info->max_refid = ix->img.max_refid;
+    info->hash_len = H.img.hash_len;
+    info->max_refid = H.img.max_refid;
     info->device = ix->device;
     for (int t = 0; t < 2; t++) {
-        info->doubly_flag[t] = ix->doubly_flag[t];
-        info->n_leaves[t] = ix->img.n_leaves[t];
-        info->n_file_buckets[t] = ix->n_file_buckets[t];
+        info->doubly_flag[t] = H.doubly_flag[t];
+        info->n_leaves[t] = H.img.n_leaves[t];
+        info->n_file_buckets[t] = H.n_file_buckets[t];
     }
-    info->n_trie_nodes = ix->img.nodes.empty() ? ix->n_trie_nodes : ix->img.nodes.size() - 1;
-    info->n_keys = ix->img.n_keys;
-    info->n_table_buckets = ix->img.n_buckets_alloc;
-    info->n_overflowed = ix->img.n_overflowed;
-    info->max_chain = ix->img.max_chain;
+    info->n_trie_nodes = H.n_trie_nodes;
+    info->n_keys = H.img.n_keys;
+    info->n_table_buckets = H.img.n_buckets_alloc;
+    info->n_overflowed = H.img.n_overflowed;
+    info->max_chain = H.img.max_chain;
     info->device_bytes = ix->device_bytes;
-    info->reserved_ = ix->from_cache ? 1u : 0u;
+    info->reserved_ = H.from_cache ? 1u : 0u;
     return CQ_OK;
 }
 
 int cq_index_leaves(const cq_index *ix, int table, cq_leaf *out)
 {
     if (!ix || !out || table < 0 || table > 1) return fail(CQ_ERR_ARG, "cq_index_leaves: bad argument");
-    const auto &lv = ix->tab[table].leaves;
+    const auto &lv = ix->H->tab[table].leaves;
     if (!lv.empty()) memcpy(out, lv.data(), lv.size() * sizeof(cq_leaf));
     return CQ_OK;
 }
@@ -303,8 +395,8 @@ int cq_index_leaves(const cq_index *ix, int table, cq_leaf *out)
 int cq_index_probe(const cq_index *ix, uint64_t hv, uint32_t *code_u, uint32_t *code_d, uint32_t *chain)
 {
     if (!ix || !code_u || !code_d) return fail(CQ_ERR_ARG, "cq_index_probe: NULL argument");
-    if (!ix->img.table) return fail(CQ_ERR_ARG, "cq_index_probe: host image was released");
-    cq::image_lookup(ix->img, hv, *code_u, *code_d, chain);
+    if (!ix->H->img.table) return fail(CQ_ERR_ARG, "cq_index_probe: host image was released");
+    cq::image_lookup(ix->H->img, hv, *code_u, *code_d, chain);
     return CQ_OK;
 }
 
@@ -317,6 +409,19 @@ void cq_index_free(cq_index *ix)
 
 uint64_t cq_counter_words(uint32_t n_genomes) { return 2ull * ((uint64_t)n_genomes + 1) + CQ_CTR_EXTRA; }
 
+int cq_host_alloc(void **p, size_t bytes)
+{
+    if (!p) return fail(CQ_ERR_ARG, "cq_host_alloc: NULL argument");
+    *p = nullptr;
+    CQ_HIP(hipHostMalloc(p, bytes ? bytes : 1, hipHostMallocDefault));
+    return CQ_OK;
+}
+
+void cq_host_free(void *p)
+{
+    if (p) (void)hipHostFree(p);
+}
+
 int cq_query_device(cq_index *ix, int mode, const uint32_t *d_packed, const uint8_t *d_lens,
                     uint64_t n_reads, uint32_t stride_words, uint32_t max_len, uint32_t n_genomes,
                     uint64_t *d_counters, uint32_t *d_rcount, void *stream)
@@ -327,19 +432,21 @@ int cq_query_device(cq_index *ix, int mode, const uint32_t *d_packed, const uint
     if (!d_counters || (n_reads && (!d_packed || !d_lens)) || stride_words == 0 || (stride_words & 3u) || stride_words > 16)
         return fail(CQ_ERR_ARG, "cq_query_device: bad argument");
     if (n_reads > 0x7FFFFFFFull) return fail(CQ_ERR_ARG, "cq_query_device: more than 2^31-1 reads in one call");
-    if (ix->img.max_refid > n_genomes)
-        return fail(CQ_ERR_RANGE, "index holds refID " + std::to_string(ix->img.max_refid) + " > n_genomes");
+    const cq::FlatImage &img = ix->H->img;
+    if (img.max_refid > n_genomes)
+        return fail(CQ_ERR_RANGE, "index holds refID " + std::to_string(img.max_refid) + " > n_genomes");
     if (n_reads == 0) return CQ_OK;
     hipStream_t st = (hipStream_t)stream;
     CQ_HIP(hipSetDevice(ix->device));
     if (ix->ovf_cap < n_reads) {   // grow the slow-path list (outside steady state)
+        CQ_HIP(hipDeviceSynchronize());   // an earlier launch may still be using the old list
         if (ix->d_ovf_list) CQ_HIP(hipFree(ix->d_ovf_list));
         ix->d_ovf_list = nullptr;
         CQ_HIP(hipMalloc((void **)&ix->d_ovf_list, n_reads * sizeof(uint32_t)));
         ix->ovf_cap = n_reads;
     }
     CQ_HIP(hipMemsetAsync(ix->d_ovf_count, 0, sizeof(uint32_t), st));
-    const uint32_t h = ix->img.hash_len;
+    const uint32_t h = img.hash_len;
     if (max_len == 0 || max_len > stride_words * 16) max_len = stride_words * 16;
     if (max_len > 255) max_len = 255;
     cq::QueryArgs a{};
@@ -357,20 +464,47 @@ int cq_query_device(cq_index *ix, int mode, const uint32_t *d_packed, const uint
     a.ovf_cap = (uint32_t)ix->ovf_cap;
     a.pair_keys = ix->d_pair_keys;
     a.pair_cnts = ix->d_pair_cnts;
-    a.pair_cap = kPairCap;
+    a.pair_cap = ix->pair_cap;
     a.stamps = ix->d_stamps;   // only written by diagnostic (CQ_STAMPS) builds
-    CQ_HIP(cq::launch_classify(ix->dev, a, ix->n_cus, st, ix->ev0, ix->ev1));
+    CQ_HIP(cq::launch_classify(ix->dev, a, ix->n_cus, st, ix->ev0, ix->ev_mid, ix->ev1));
     ix->ev_valid = true;
+    return CQ_OK;
+}
+
+int cq_last_kernel_times(cq_index *ix, float *fast_ms, float *slow_ms)
+{
+    if (!ix) return fail(CQ_ERR_ARG, "cq_last_kernel_times: NULL argument");
+    if (!ix->ev_valid) return fail(CQ_ERR_ARG, "cq_last_kernel_times: no kernel has been launched on this handle");
+    CQ_HIP(hipEventSynchronize(ix->ev1));
+    float a = 0.f, b = 0.f;
+    CQ_HIP(hipEventElapsedTime(&a, ix->ev0, ix->ev_mid));
+    CQ_HIP(hipEventElapsedTime(&b, ix->ev_mid, ix->ev1));
+    if (fast_ms) *fast_ms = a;
+    if (slow_ms) *slow_ms = b;
     return CQ_OK;
 }
 
 int cq_last_kernel_ms(cq_index *ix, float *ms)
 {
-    if (!ix || !ms) return fail(CQ_ERR_ARG, "cq_last_kernel_ms: NULL argument");
-    if (!ix->ev_valid) return fail(CQ_ERR_ARG, "cq_last_kernel_ms: no kernel has been launched on this handle");
-    CQ_HIP(hipEventSynchronize(ix->ev1));
-    CQ_HIP(hipEventElapsedTime(ms, ix->ev0, ix->ev1));
+    if (!ms) return fail(CQ_ERR_ARG, "cq_last_kernel_ms: NULL argument");
+    float a = 0.f, b = 0.f;
+    int rc = cq_last_kernel_times(ix, &a, &b);
+    if (rc != CQ_OK) return rc;
+    *ms = a + b;
     return CQ_OK;
+}
+
+int cq_pairs_reserve(cq_index *ix, uint64_t n_slots)
+{
+    if (!ix) return fail(CQ_ERR_ARG, "cq_pairs_reserve: NULL handle");
+    if (ix->device < 0) return fail(CQ_ERR_NO_DEVICE, "index was loaded host-only");
+    if (n_slots > (1ull << 30)) return fail(CQ_ERR_LIMIT, "cq_pairs_reserve: more than 2^30 slots");
+    uint32_t s = 16;
+    while (s < n_slots) s <<= 1;
+    CQ_HIP(hipSetDevice(ix->device));
+    CQ_HIP(hipDeviceSynchronize());
+    if (s == ix->pair_cap) return pairs_clear(ix);
+    return pairs_alloc(ix, s);
 }
 
 int cq_pairs_fetch(cq_index *ix, uint32_t *pair_a, uint32_t *pair_b, uint64_t *pair_cnt,
@@ -380,15 +514,15 @@ int cq_pairs_fetch(cq_index *ix, uint32_t *pair_a, uint32_t *pair_b, uint64_t *p
     if (ix->device < 0) return fail(CQ_ERR_NO_DEVICE, "index was loaded host-only");
     CQ_HIP(hipSetDevice(ix->device));
     CQ_HIP(hipDeviceSynchronize());
-    std::vector<uint64_t> k(kPairCap), c(kPairCap);
-    CQ_HIP(hipMemcpy(k.data(), ix->d_pair_keys, (size_t)kPairCap * 8, hipMemcpyDeviceToHost));
-    CQ_HIP(hipMemcpy(c.data(), ix->d_pair_cnts, (size_t)kPairCap * 8, hipMemcpyDeviceToHost));
-    CQ_HIP(hipMemset(ix->d_pair_keys, 0xFF, (size_t)kPairCap * 8));
-    CQ_HIP(hipMemset(ix->d_pair_cnts, 0, (size_t)kPairCap * 8));
+    const size_t cap = ix->pair_cap;
+    std::vector<uint64_t> k(cap), c(cap);
+    CQ_HIP(hipMemcpy(k.data(), ix->d_pair_keys, cap * 8, hipMemcpyDeviceToHost));
+    CQ_HIP(hipMemcpy(c.data(), ix->d_pair_cnts, cap * 8, hipMemcpyDeviceToHost));
+    const bool want = pair_a && pair_b && pair_cnt;
     uint64_t n = 0;
-    for (uint32_t i = 0; i < kPairCap; i++) {
+    for (size_t i = 0; i < cap; i++) {
         if (k[i] == CQ_EMPTY_KEY) continue;
-        if (n < pair_cap && pair_a && pair_b && pair_cnt) {
+        if (want && n < pair_cap) {
             pair_a[n] = (uint32_t)(k[i] >> 32);
             pair_b[n] = (uint32_t)k[i];
             pair_cnt[n] = c[i];
@@ -396,55 +530,87 @@ int cq_pairs_fetch(cq_index *ix, uint32_t *pair_a, uint32_t *pair_b, uint64_t *p
         n++;
     }
     *n_pairs = n;
-    if (n > pair_cap) return fail(CQ_ERR_LIMIT, "more distinct pairs than pair_cap");
-    return CQ_OK;
+    if (!want) return CQ_OK;                     // count only: nothing copied, nothing cleared
+    if (n > pair_cap)
+        return fail(CQ_ERR_LIMIT, "more distinct pairs than pair_cap (nothing was cleared: call cq_pairs_fetch again with larger arrays)");
+    return pairs_clear(ix);
 }
+
+}  // extern "C"
 
 namespace {
 
-// Grow one staging slot to hold n reads of sw words.
-int slot_reserve(cq_index::Slot &sl, uint64_t n, uint32_t sw)
+// Grow one staging slot: device rows for n reads of sw words, and (host_too) the pinned host side.
+int slot_reserve(cq_index::Slot &sl, uint64_t n, uint32_t sw, bool host_too)
 {
     const size_t words = (size_t)n * sw;
-    if (sl.cap_words < words) {
-        if (sl.h_packed) (void)hipHostFree(sl.h_packed);
+    if (sl.cap_words_d < words) {
         if (sl.d_packed) (void)hipFree(sl.d_packed);
-        sl.h_packed = nullptr; sl.d_packed = nullptr; sl.cap_words = 0;
-        CQ_HIP(hipHostMalloc((void **)&sl.h_packed, words * 4, hipHostMallocDefault));
+        sl.d_packed = nullptr; sl.cap_words_d = 0;
         CQ_HIP(hipMalloc((void **)&sl.d_packed, words * 4));
-        sl.cap_words = words;
+        sl.cap_words_d = words;
     }
-    if (sl.cap_reads < n) {
-        if (sl.h_lens) (void)hipHostFree(sl.h_lens);
+    if (sl.cap_reads_d < n) {
         if (sl.d_lens) (void)hipFree(sl.d_lens);
-        sl.h_lens = nullptr; sl.d_lens = nullptr; sl.cap_reads = 0;
-        CQ_HIP(hipHostMalloc((void **)&sl.h_lens, n, hipHostMallocDefault));
+        sl.d_lens = nullptr; sl.cap_reads_d = 0;
         CQ_HIP(hipMalloc((void **)&sl.d_lens, n));
-        sl.cap_reads = n;
+        sl.cap_reads_d = n;
+    }
+    if (host_too && sl.cap_words_h < words) {
+        if (sl.h_packed) (void)hipHostFree(sl.h_packed);
+        sl.h_packed = nullptr; sl.cap_words_h = 0;
+        CQ_HIP(hipHostMalloc((void **)&sl.h_packed, words * 4, hipHostMallocDefault));
+        sl.cap_words_h = words;
+    }
+    if (host_too && sl.cap_reads_h < n) {
+        if (sl.h_lens) (void)hipHostFree(sl.h_lens);
+        sl.h_lens = nullptr; sl.cap_reads_h = 0;
+        CQ_HIP(hipHostMalloc((void **)&sl.h_lens, n, hipHostMallocDefault));
+        sl.cap_reads_h = n;
     }
     if (!sl.copied) CQ_HIP(hipEventCreateWithFlags(&sl.copied, hipEventDisableTiming));
     if (!sl.done) CQ_HIP(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
     return CQ_OK;
 }
 
-}  // namespace
+// Where the reads of a host-fed query come from: ASCII as FqReader::readFastq leaves them
+// (bases + offsets), or rows already packed by cq_pack_reads (packed + lens).
+struct Feed {
+    const uint8_t *bases = nullptr;
+    const uint64_t *offsets = nullptr;
+    const uint32_t *packed = nullptr;
+    const uint8_t *lens = nullptr;
+    uint32_t sw = 0, max_len = 0;
+};
 
-int cq_query(cq_index *ix, int mode, const uint8_t *bases, const uint64_t *offsets,
-             uint64_t n_reads, uint32_t n_genomes, cq_counts *out)
+int query_checks(const cq_index *ix, int mode, uint32_t n_genomes, const cq_counts *out, const char *who)
 {
-    if (!ix || !out || !offsets) return fail(CQ_ERR_ARG, "cq_query: NULL argument");
-    if (!out->cnt_u || !out->cnt_d) return fail(CQ_ERR_ARG, "cq_query: cnt_u / cnt_d must be provided");
-    if (mode == CQ_MODE_P && ((!out->rcount_u && ix->img.n_leaves[0]) || (!out->rcount_d && ix->img.n_leaves[1])))
-        return fail(CQ_ERR_ARG, "cq_query: rcount_u / rcount_d are mandatory in CQ_MODE_P (the ILP reads them)");
+    if (!out->cnt_u || !out->cnt_d) return fail(CQ_ERR_ARG, std::string(who) + ": cnt_u / cnt_d must be provided");
+    const cq::FlatImage &img = ix->H->img;
+    if (mode != CQ_MODE_P && mode != CQ_MODE_SC) return fail(CQ_ERR_ARG, std::string(who) + ": unknown mode");
+    if (mode == CQ_MODE_P && ((!out->rcount_u && img.n_leaves[0]) || (!out->rcount_d && img.n_leaves[1])))
+        return fail(CQ_ERR_ARG, std::string(who) + ": rcount_u / rcount_d are mandatory in CQ_MODE_P (the ILP reads them)");
     if (ix->device < 0) return fail(CQ_ERR_NO_DEVICE, "index was loaded host-only (CQ_DEVICE_NONE); no CPU classify path exists");
-    if (ix->img.max_refid > n_genomes)
-        return fail(CQ_ERR_RANGE, "index holds refID " + std::to_string(ix->img.max_refid) + " > n_genomes");
+    if (img.max_refid > n_genomes)
+        return fail(CQ_ERR_RANGE, "index holds refID " + std::to_string(img.max_refid) + " > n_genomes");
+    return CQ_OK;
+}
+
+// Classify reads [lo, hi) of `f` on ix's device into the handle's own counter block (d_ctr) and
+// rcount array (d_rc), both zeroed first: resetCounters + query64_* (query.cpp:1820-1840, 458-1080).
+// Chunks of 2 M reads alternate between two staging slots:
+//   CPU   pack(c+1) ........ pack(c+2) ........          (ASCII feed only)
+//   copy           H2D(c+1) ...........H2D(c+2)
+//   comp  kernel(c) ........ kernel(c+1) .......
+// Returns with everything complete on the device (s_comp synchronised).
+int classify_range(cq_index *ix, int mode, const Feed &f, uint64_t lo, uint64_t hi, uint32_t n_genomes)
+{
+    const cq::FlatImage &img = ix->H->img;
     CQ_HIP(hipSetDevice(ix->device));
     if (!ix->s_copy) CQ_HIP(hipStreamCreateWithFlags(&ix->s_copy, hipStreamNonBlocking));
     if (!ix->s_comp) CQ_HIP(hipStreamCreateWithFlags(&ix->s_comp, hipStreamNonBlocking));
-
-    const uint64_t G1 = (uint64_t)n_genomes + 1, cw = cq_counter_words(n_genomes);
-    const uint64_t nl = ix->img.n_leaves[0] + ix->img.n_leaves[1];
+    const uint64_t cw = cq_counter_words(n_genomes);
+    const uint64_t nl = img.n_leaves[0] + img.n_leaves[1];
     if (ix->ctr_cap < cw) {
         if (ix->d_ctr) (void)hipFree(ix->d_ctr);
         ix->d_ctr = nullptr; ix->ctr_cap = 0;
@@ -463,31 +629,39 @@ int cq_query(cq_index *ix, int mode, const uint8_t *bases, const uint64_t *offse
         d_rc = ix->d_rc;
         CQ_HIP(hipMemsetAsync(d_rc, 0, nl * 4, ix->s_comp));
     }
-
-    // One call = one FASTQ.  Chunks of 2 M reads alternate between two staging slots:
-    //   CPU   pack(c+1) ........ pack(c+2) ........
-    //   copy           H2D(c+1) ...........H2D(c+2)
-    //   comp  kernel(c) ........ kernel(c+1) .......
-    const uint64_t kChunk = 1ull << 21;
+    const bool ascii = f.packed == nullptr;
     int rc = CQ_OK;
     uint64_t c = 0;
-    for (uint64_t c0 = 0; c0 < n_reads && rc == CQ_OK; c0 += kChunk, c++) {
+    for (uint64_t c0 = lo; c0 < hi && rc == CQ_OK; c0 += kChunk, c++) {
         cq_index::Slot &sl = ix->slot[c & 1];
-        const uint64_t n = std::min(kChunk, n_reads - c0);
-        uint64_t max_len = 0;
-        for (uint64_t r = c0; r < c0 + n; r++) {
-            const uint64_t l = offsets[r + 1] - offsets[r];
-            if (l <= 255 && l > max_len) max_len = l;
+        const uint64_t n = std::min(kChunk, hi - c0);
+        uint64_t max_len = f.max_len;
+        uint32_t sw = f.sw;
+        if (ascii) {
+            max_len = 0;
+            for (uint64_t r = c0; r < c0 + n; r++) {
+                const uint64_t l = f.offsets[r + 1] - f.offsets[r];
+                if (l <= 255 && l > max_len) max_len = l;
+            }
+            sw = cq_pack_stride_words((uint32_t)max_len);
         }
-        const uint32_t sw = cq_pack_stride_words((uint32_t)max_len);
         if (sl.done) CQ_HIP(hipEventSynchronize(sl.done));      // the kernel that last used this slot
-        rc = slot_reserve(sl, n, sw);
+        rc = slot_reserve(sl, n, sw, ascii);
         if (rc != CQ_OK) break;
-        uint64_t sk = 0;
-        rc = cq_pack_reads(bases, offsets + c0, n, ix->img.hash_len, sw, sl.h_packed, sl.h_lens, &sk);
-        if (rc != CQ_OK) { fail(rc, "cq_pack_reads failed"); break; }
-        CQ_HIP(hipMemcpyAsync(sl.d_packed, sl.h_packed, (size_t)n * sw * 4, hipMemcpyHostToDevice, ix->s_copy));
-        CQ_HIP(hipMemcpyAsync(sl.d_lens, sl.h_lens, n, hipMemcpyHostToDevice, ix->s_copy));
+        const uint32_t *src_rows = nullptr;
+        const uint8_t *src_lens = nullptr;
+        if (ascii) {
+            uint64_t sk = 0;
+            rc = cq_pack_reads(f.bases, f.offsets + c0, n, img.hash_len, sw, sl.h_packed, sl.h_lens, &sk);
+            if (rc != CQ_OK) { fail(rc, "cq_pack_reads failed"); break; }
+            src_rows = sl.h_packed;
+            src_lens = sl.h_lens;
+        } else {
+            src_rows = f.packed + (size_t)c0 * sw;
+            src_lens = f.lens + c0;
+        }
+        CQ_HIP(hipMemcpyAsync(sl.d_packed, src_rows, (size_t)n * sw * 4, hipMemcpyHostToDevice, ix->s_copy));
+        CQ_HIP(hipMemcpyAsync(sl.d_lens, src_lens, n, hipMemcpyHostToDevice, ix->s_copy));
         CQ_HIP(hipEventRecord(sl.copied, ix->s_copy));
         CQ_HIP(hipStreamWaitEvent(ix->s_comp, sl.copied, 0));
         rc = cq_query_device(ix, mode, sl.d_packed, sl.d_lens, n, sw, (uint32_t)max_len, n_genomes, ix->d_ctr, d_rc,
@@ -496,15 +670,55 @@ int cq_query(cq_index *ix, int mode, const uint8_t *bases, const uint64_t *offse
         CQ_HIP(hipEventRecord(sl.done, ix->s_comp));
     }
     if (hipStreamSynchronize(ix->s_comp) != hipSuccess && rc == CQ_OK) rc = fail(CQ_ERR_HIP, "classify kernel failed");
-    if (rc != CQ_OK) return rc;
+    return rc;
+}
 
+// D2H of `bytes` from device memory into a caller array that may be pageable.  Pinned arrays
+// (cq_host_alloc) take one direct copy; pageable ones go through two pinned bounce buffers, the copy
+// of piece k+1 overlapping the memcpy of piece k -- a pageable hipMemcpy of the few hundred MB of
+// rcount of a 1000-genome index runs at a fraction of the link rate otherwise.
+int copy_out(cq_index *ix, void *dst, const void *d_src, size_t bytes)
+{
+    if (!bytes) return CQ_OK;
+    hipPointerAttribute_t at;
+    const bool pinned = hipPointerGetAttributes(&at, dst) == hipSuccess && at.type == hipMemoryTypeHost;
+    if (!pinned) (void)hipGetLastError();   // plain malloc memory: the attribute query leaves a sticky error behind
+    if (pinned || bytes <= (1u << 20)) {
+        CQ_HIP(hipMemcpy(dst, d_src, bytes, hipMemcpyDeviceToHost));
+        return CQ_OK;
+    }
+    for (int b = 0; b < 2; b++) {
+        if (!ix->h_bounce[b]) CQ_HIP(hipHostMalloc(&ix->h_bounce[b], kBounce, hipHostMallocDefault));
+        if (!ix->ev_bounce[b]) CQ_HIP(hipEventCreateWithFlags(&ix->ev_bounce[b], hipEventDisableTiming));
+    }
+    const size_t np = (bytes + kBounce - 1) / kBounce;
+    auto piece = [&](size_t k) { return std::min(kBounce, bytes - k * kBounce); };
+    CQ_HIP(hipMemcpyAsync(ix->h_bounce[0], d_src, piece(0), hipMemcpyDeviceToHost, ix->s_copy));
+    CQ_HIP(hipEventRecord(ix->ev_bounce[0], ix->s_copy));
+    for (size_t k = 0; k < np; k++) {
+        if (k + 1 < np) {
+            CQ_HIP(hipMemcpyAsync(ix->h_bounce[(k + 1) & 1], (const char *)d_src + (k + 1) * kBounce, piece(k + 1),
+                                  hipMemcpyDeviceToHost, ix->s_copy));
+            CQ_HIP(hipEventRecord(ix->ev_bounce[(k + 1) & 1], ix->s_copy));
+        }
+        CQ_HIP(hipEventSynchronize(ix->ev_bounce[k & 1]));
+        memcpy((char *)dst + k * kBounce, ix->h_bounce[k & 1], piece(k));
+    }
+    return CQ_OK;
+}
+
+// Counter block + rcount of ix (device) -> the caller's cq_counts.  Pair counts are NOT handled here.
+int fetch_counts(cq_index *ix, int mode, uint32_t n_genomes, cq_counts *out, uint64_t *flags)
+{
+    const cq::FlatImage &img = ix->H->img;
+    const uint64_t G1 = (uint64_t)n_genomes + 1, cw = cq_counter_words(n_genomes);
+    CQ_HIP(hipSetDevice(ix->device));
     std::vector<uint64_t> ctr(cw, 0);
     CQ_HIP(hipMemcpy(ctr.data(), ix->d_ctr, cw * 8, hipMemcpyDeviceToHost));
-    if (d_rc) {
-        if (ix->img.n_leaves[0])
-            CQ_HIP(hipMemcpy(out->rcount_u, d_rc, ix->img.n_leaves[0] * 4, hipMemcpyDeviceToHost));
-        if (ix->img.n_leaves[1])
-            CQ_HIP(hipMemcpy(out->rcount_d, d_rc + ix->img.n_leaves[0], ix->img.n_leaves[1] * 4, hipMemcpyDeviceToHost));
+    if (mode == CQ_MODE_P && ix->d_rc) {
+        int rc = copy_out(ix, out->rcount_u, ix->d_rc, img.n_leaves[0] * 4);
+        if (rc == CQ_OK) rc = copy_out(ix, out->rcount_d, ix->d_rc + img.n_leaves[0], img.n_leaves[1] * 4);
+        if (rc != CQ_OK) return rc;
     }
     memcpy(out->cnt_u, ctr.data(), G1 * 8);
     memcpy(out->cnt_d, ctr.data() + G1, G1 * 8);
@@ -512,14 +726,341 @@ int cq_query(cq_index *ix, int mode, const uint8_t *bases, const uint64_t *offse
     out->nconf = ctr[CQ_CTR_NCONF(n_genomes)];
     out->nskipped = ctr[CQ_CTR_NSKIP(n_genomes)];
     out->n_pairs = 0;
-    if (mode == CQ_MODE_SC) {
-        if (ctr[CQ_CTR_FLAGS(n_genomes)] & 1ull) return fail(CQ_ERR_LIMIT, "device pair table full");
+    *flags = ctr[CQ_CTR_FLAGS(n_genomes)];
+    return CQ_OK;
+}
+
+// One host-fed query on one device.  In SC mode a full pair map (flags word != 0: some
+// read_cnts_b increments were dropped) is grown x4 and the whole range is classified again.
+int query_one(cq_index *ix, int mode, const Feed &f, uint64_t n_reads, uint32_t n_genomes, cq_counts *out)
+{
+    for (;;) {
+        int rc = classify_range(ix, mode, f, 0, n_reads, n_genomes);
+        if (rc != CQ_OK) return rc;
+        uint64_t flags = 0;
+        rc = fetch_counts(ix, mode, n_genomes, out, &flags);
+        if (rc != CQ_OK) return rc;
+        if (mode != CQ_MODE_SC) return CQ_OK;
+        if (flags != 0) {
+            if (ix->pair_cap >= (1u << 30)) { (void)pairs_clear(ix); return fail(CQ_ERR_LIMIT, "device pair table full at 2^30 slots"); }
+            rc = pairs_alloc(ix, ix->pair_cap << 2);
+            if (rc != CQ_OK) return rc;
+            continue;
+        }
         uint64_t np = 0;
         rc = cq_pairs_fetch(ix, out->pair_a, out->pair_b, out->pair_cnt, out->pair_cap, &np);
         out->n_pairs = np;
+        return rc;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int cq_query(cq_index *ix, int mode, const uint8_t *bases, const uint64_t *offsets,
+             uint64_t n_reads, uint32_t n_genomes, cq_counts *out)
+{
+    if (!ix || !out || !offsets) return fail(CQ_ERR_ARG, "cq_query: NULL argument");
+    int rc = query_checks(ix, mode, n_genomes, out, "cq_query");
+    if (rc != CQ_OK) return rc;
+    Feed f;
+    f.bases = bases;
+    f.offsets = offsets;
+    return query_one(ix, mode, f, n_reads, n_genomes, out);
+}
+
+int cq_query_packed(cq_index *ix, int mode, const uint32_t *packed, const uint8_t *lens, uint64_t n_reads,
+                    uint32_t stride_words, uint32_t max_len, uint32_t n_genomes, cq_counts *out)
+{
+    if (!ix || !out || (n_reads && (!packed || !lens))) return fail(CQ_ERR_ARG, "cq_query_packed: NULL argument");
+    if (stride_words == 0 || (stride_words & 3u) || stride_words > 16) return fail(CQ_ERR_ARG, "cq_query_packed: bad stride");
+    int rc = query_checks(ix, mode, n_genomes, out, "cq_query_packed");
+    if (rc != CQ_OK) return rc;
+    Feed f;
+    f.packed = packed;
+    f.lens = lens;
+    f.sw = stride_words;
+    f.max_len = max_len;
+    return query_one(ix, mode, f, n_reads, n_genomes, out);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Multi-GPU, one process per GPU: the caller (an MPI-style launcher, torchrun, ...) moves the
+ * 128-byte id from rank 0 to the others by whatever means it has.
+ * ------------------------------------------------------------------------------------------ */
+
+int cq_comm_unique_id(uint8_t *id)
+{
+    if (!id) return fail(CQ_ERR_ARG, "cq_comm_unique_id: NULL argument");
+    static_assert(CQ_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "id size");
+    ncclUniqueId u;
+    CQ_NCCL(ncclGetUniqueId(&u));
+    memcpy(id, u.internal, CQ_COMM_ID_BYTES);
+    return CQ_OK;
+}
+
+int cq_comm_init_rank(cq_index *ix, const uint8_t *id, int rank, int n_ranks, cq_comm **out)
+{
+    if (!ix || !id || !out || n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail(CQ_ERR_ARG, "cq_comm_init_rank: bad argument");
+    if (ix->device < 0) return fail(CQ_ERR_NO_DEVICE, "index was loaded host-only");
+    *out = nullptr;
+    CQ_HIP(hipSetDevice(ix->device));
+    ncclUniqueId u;
+    memcpy(u.internal, id, CQ_COMM_ID_BYTES);
+    cq_comm *c = new (std::nothrow) cq_comm();
+    if (!c) return fail(CQ_ERR_NOMEM, "out of memory");
+    ncclResult_t r = ncclCommInitRank(&c->comm, n_ranks, u, rank);
+    if (r != ncclSuccess) { delete c; return fail(CQ_ERR_COMM, std::string("ncclCommInitRank: ") + ncclGetErrorString(r)); }
+    c->device = ix->device;
+    c->rank = rank;
+    c->n_ranks = n_ranks;
+    *out = c;
+    return CQ_OK;
+}
+
+int cq_counts_allreduce(cq_comm *c, uint64_t *d_counters, uint64_t n_counter_words, uint32_t *d_rcount,
+                        uint64_t n_rcount, void *stream)
+{
+    if (!c || !d_counters || !n_counter_words) return fail(CQ_ERR_ARG, "cq_counts_allreduce: bad argument");
+    CQ_HIP(hipSetDevice(c->device));
+    hipStream_t st = (hipStream_t)stream;
+    // every word of the block is a count (the flags word too: a count of lost increments), so one sum serves all
+    CQ_NCCL(ncclGroupStart());
+    ncclResult_t r1 = ncclAllReduce(d_counters, d_counters, n_counter_words, ncclUint64, ncclSum, c->comm, st);
+    ncclResult_t r2 = (d_rcount && n_rcount) ? ncclAllReduce(d_rcount, d_rcount, n_rcount, ncclUint32, ncclSum, c->comm, st) : ncclSuccess;
+    CQ_NCCL(ncclGroupEnd());
+    if (r1 != ncclSuccess) return fail(CQ_ERR_COMM, std::string("ncclAllReduce(counters): ") + ncclGetErrorString(r1));
+    if (r2 != ncclSuccess) return fail(CQ_ERR_COMM, std::string("ncclAllReduce(rcount): ") + ncclGetErrorString(r2));
+    return CQ_OK;
+}
+
+int cq_comm_info(const cq_comm *c, int *rank, int *n_ranks)
+{
+    if (!c) return fail(CQ_ERR_ARG, "cq_comm_info: NULL argument");
+    if (rank) *rank = c->rank;
+    if (n_ranks) *n_ranks = c->n_ranks;
+    return CQ_OK;
+}
+
+void cq_comm_free(cq_comm *c)
+{
+    if (!c) return;
+    if (c->comm) { (void)hipSetDevice(c->device); (void)ncclCommDestroy(c->comm); }
+    delete c;
+}
+
+int cq_shard_range(uint64_t n_reads, int rank, int n_ranks, uint64_t *lo, uint64_t *hi)
+{
+    if (n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail(CQ_ERR_ARG, "cq_shard_range: rank out of range");
+    // contiguous ranges [n*p/P, n*(p+1)/P); 128-bit product: n_reads * P may pass 2^64
+    const unsigned __int128 n = n_reads;
+    if (lo) *lo = (uint64_t)(n * (unsigned)rank / (unsigned)n_ranks);
+    if (hi) *hi = (uint64_t)(n * ((unsigned)rank + 1u) / (unsigned)n_ranks);
+    return CQ_OK;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Multi-GPU, one process: one host thread per device.
+ * ------------------------------------------------------------------------------------------ */
+
+void cq_multi_free(cq_multi *m)
+{
+    if (!m) return;
+    for (size_t i = 0; i < m->comms.size(); i++)
+        if (m->comms[i]) { (void)hipSetDevice(m->ix[m->leaders[i]]->device); (void)ncclCommDestroy(m->comms[i]); }
+    for (cq_index *ix : m->ix) cq_index_free(ix);
+    delete m;
+}
+
+int cq_multi_load(const char *path_u, const char *path_d, const int *devices, int n_dev, cq_multi **out)
+{
+    if (!path_u || !devices || n_dev < 1 || n_dev > 64 || !out) return fail(CQ_ERR_ARG, "cq_multi_load: bad argument");
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(CQ_ERR_NO_DEVICE, "no HIP device available");
+    double budget = 1e30;
+    for (int i = 0; i < n_dev; i++) {
+        if (devices[i] < 0 || devices[i] >= ndev) return fail(CQ_ERR_NO_DEVICE, "cq_multi_load: device ordinal out of range");
+        int same = 0;
+        for (int j = 0; j < n_dev; j++) same += devices[j] == devices[i];
+        budget = std::min(budget, table_budget(devices[i]) / same);
+    }
+    LoadTimer lt;
+    std::shared_ptr<HostIndex> H;
+    int rc = prepare_host(path_u, path_d, budget, H, lt);   // decode + layout ONCE
+    if (rc != CQ_OK) return rc;
+    cq_multi *m = new (std::nothrow) cq_multi();
+    if (!m) return fail(CQ_ERR_NOMEM, "out of memory");
+    for (int i = 0; i < n_dev; i++) {
+        cq_index *ix = new (std::nothrow) cq_index();
+        if (!ix) { cq_multi_free(m); return fail(CQ_ERR_NOMEM, "out of memory"); }
+        ix->H = H;
+        ix->device = devices[i];
+        m->ix.push_back(ix);
+    }
+    // upload to all devices at once (one host thread each; every GPU has its own PCIe link)
+    std::vector<int> rcs(n_dev, CQ_OK);
+    std::vector<std::string> errs(n_dev);
+    {
+        std::vector<std::thread> th;
+        for (int i = 0; i < n_dev; i++)
+            th.emplace_back([&, i] { rcs[i] = upload(m->ix[i]); if (rcs[i] != CQ_OK) errs[i] = g_err; });
+        for (auto &x : th) x.join();
+    }
+    lt.lap("upload (all devices)");
+    for (int i = 0; i < n_dev; i++)
+        if (rcs[i] != CQ_OK) { cq_multi_free(m); return fail(rcs[i], errs[i]); }
+    drop_host_image(*H);
+    // Handles on the same device form a group (rehearsal on a box with fewer GPUs than shards): they
+    // are summed by a device kernel; the group leaders -- distinct devices -- meet in the RCCL all-reduce.
+    m->leader_of.assign(n_dev, 0);
+    std::vector<int> devs;
+    for (int i = 0; i < n_dev; i++) {
+        int l = i;
+        for (int j = 0; j < i; j++) if (devices[j] == devices[i]) { l = j; break; }
+        m->leader_of[i] = l;
+        if (l == i) { m->leaders.push_back(i); devs.push_back(devices[i]); }
+    }
+    m->comms.assign(m->leaders.size(), nullptr);
+    ncclResult_t r = ncclCommInitAll(m->comms.data(), (int)devs.size(), devs.data());
+    if (r != ncclSuccess) { cq_multi_free(m); return fail(CQ_ERR_COMM, std::string("ncclCommInitAll: ") + ncclGetErrorString(r)); }
+    lt.lap("ncclCommInitAll");
+    *out = m;
+    return CQ_OK;
+}
+
+int cq_multi_size(const cq_multi *m) { return m ? (int)m->ix.size() : 0; }
+
+cq_index *cq_multi_index(cq_multi *m, int i)
+{
+    if (!m || i < 0 || i >= (int)m->ix.size()) { fail(CQ_ERR_ARG, "cq_multi_index: bad argument"); return nullptr; }
+    return m->ix[i];
+}
+
+}  // extern "C"
+
+namespace {
+
+int multi_query(cq_multi *m, int mode, const Feed &f, uint64_t n_reads, uint32_t n_genomes, cq_counts *out, const char *who)
+{
+    const int P = (int)m->ix.size();
+    for (int i = 0; i < P; i++) {
+        int rc = query_checks(m->ix[i], mode, n_genomes, out, who);
         if (rc != CQ_OK) return rc;
     }
-    return CQ_OK;
+    const cq::FlatImage &img = m->ix[0]->H->img;
+    const uint64_t cw = cq_counter_words(n_genomes);
+    const uint64_t nl = img.n_leaves[0] + img.n_leaves[1];
+    const bool rc_on = mode == CQ_MODE_P && nl;
+    for (;;) {
+        // ---- shard p classifies reads [n*p/P, n*(p+1)/P) on its device (the loop of query.cpp:664-665)
+        std::vector<int> rcs(P, CQ_OK);
+        std::vector<std::string> errs(P);
+        {
+            std::vector<std::thread> th;
+            for (int p = 0; p < P; p++)
+                th.emplace_back([&, p] {
+                    uint64_t lo = 0, hi = 0;
+                    (void)cq_shard_range(n_reads, p, P, &lo, &hi);
+                    rcs[p] = classify_range(m->ix[p], mode, f, lo, hi, n_genomes);
+                    if (rcs[p] != CQ_OK) errs[p] = g_err;
+                });
+            for (auto &x : th) x.join();
+        }
+        for (int p = 0; p < P; p++) if (rcs[p] != CQ_OK) return fail(rcs[p], errs[p]);
+        // ---- handles that share a device: add into their group leader
+        for (int p = 0; p < P; p++) {
+            const int l = m->leader_of[p];
+            if (l == p) continue;
+            cq_index *dst = m->ix[l], *src = m->ix[p];
+            CQ_HIP(hipSetDevice(dst->device));
+            CQ_HIP(cq::launch_accumulate(dst->d_ctr, src->d_ctr, cw, rc_on ? dst->d_rc : nullptr, rc_on ? src->d_rc : nullptr,
+                                         rc_on ? nl : 0, dst->s_comp));
+            CQ_HIP(hipStreamSynchronize(dst->s_comp));
+        }
+        // ---- the exchange step: one all-reduce(sum) of the counter block and of rcount over the devices
+        CQ_NCCL(ncclGroupStart());
+        ncclResult_t bad = ncclSuccess;
+        for (size_t k = 0; k < m->leaders.size(); k++) {
+            cq_index *ix = m->ix[m->leaders[k]];
+            ncclResult_t r = ncclAllReduce(ix->d_ctr, ix->d_ctr, cw, ncclUint64, ncclSum, m->comms[k], ix->s_comp);
+            if (r == ncclSuccess && rc_on) r = ncclAllReduce(ix->d_rc, ix->d_rc, nl, ncclUint32, ncclSum, m->comms[k], ix->s_comp);
+            if (r != ncclSuccess) bad = r;
+        }
+        CQ_NCCL(ncclGroupEnd());
+        if (bad != ncclSuccess) return fail(CQ_ERR_COMM, std::string("ncclAllReduce: ") + ncclGetErrorString(bad));
+        for (size_t k = 0; k < m->leaders.size(); k++) {
+            cq_index *ix = m->ix[m->leaders[k]];
+            CQ_HIP(hipSetDevice(ix->device));
+            CQ_HIP(hipStreamSynchronize(ix->s_comp));
+        }
+        // ---- every device now holds the totals; the host takes device 0's copy (query.cpp:251-258 hand-off)
+        uint64_t flags = 0;
+        int rc = fetch_counts(m->ix[0], mode, n_genomes, out, &flags);
+        if (rc != CQ_OK) return rc;
+        if (mode != CQ_MODE_SC) return CQ_OK;
+        if (flags != 0) {   // some shard's pair map filled up: grow all of them, classify again
+            for (int p = 0; p < P; p++) {
+                cq_index *ix = m->ix[p];
+                CQ_HIP(hipSetDevice(ix->device));
+                if (ix->pair_cap >= (1u << 30)) return fail(CQ_ERR_LIMIT, "device pair table full at 2^30 slots");
+                rc = pairs_alloc(ix, ix->pair_cap << 2);
+                if (rc != CQ_OK) return rc;
+            }
+            continue;
+        }
+        // read_cnts_b: per-shard maps, merged on the host (SURVEY.md 8(e) "replicas + host merge")
+        std::map<uint64_t, uint64_t> merged;
+        for (int p = 0; p < P; p++) {
+            uint64_t np = 0;
+            rc = cq_pairs_fetch(m->ix[p], nullptr, nullptr, nullptr, 0, &np);
+            if (rc != CQ_OK) return rc;
+            std::vector<uint32_t> a(np + 1), b(np + 1);
+            std::vector<uint64_t> c(np + 1);
+            rc = cq_pairs_fetch(m->ix[p], a.data(), b.data(), c.data(), np + 1, &np);
+            if (rc != CQ_OK) return rc;
+            for (uint64_t i = 0; i < np; i++) merged[((uint64_t)a[i] << 32) | b[i]] += c[i];
+        }
+        out->n_pairs = merged.size();
+        if (merged.size() > out->pair_cap || (merged.size() && (!out->pair_a || !out->pair_b || !out->pair_cnt)))
+            return fail(CQ_ERR_LIMIT, "more distinct pairs than pair_cap");
+        uint64_t i = 0;
+        for (const auto &kv : merged) {
+            out->pair_a[i] = (uint32_t)(kv.first >> 32);
+            out->pair_b[i] = (uint32_t)kv.first;
+            out->pair_cnt[i] = kv.second;
+            i++;
+        }
+        return CQ_OK;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int cq_multi_query(cq_multi *m, int mode, const uint8_t *bases, const uint64_t *offsets, uint64_t n_reads,
+                   uint32_t n_genomes, cq_counts *out)
+{
+    if (!m || !out || !offsets) return fail(CQ_ERR_ARG, "cq_multi_query: NULL argument");
+    Feed f;
+    f.bases = bases;
+    f.offsets = offsets;
+    return multi_query(m, mode, f, n_reads, n_genomes, out, "cq_multi_query");
+}
+
+int cq_multi_query_packed(cq_multi *m, int mode, const uint32_t *packed, const uint8_t *lens, uint64_t n_reads,
+                          uint32_t stride_words, uint32_t max_len, uint32_t n_genomes, cq_counts *out)
+{
+    if (!m || !out || (n_reads && (!packed || !lens))) return fail(CQ_ERR_ARG, "cq_multi_query_packed: NULL argument");
+    if (stride_words == 0 || (stride_words & 3u) || stride_words > 16) return fail(CQ_ERR_ARG, "cq_multi_query_packed: bad stride");
+    Feed f;
+    f.packed = packed;
+    f.lens = lens;
+    f.sw = stride_words;
+    f.max_len = max_len;
+    return multi_query(m, mode, f, n_reads, n_genomes, out, "cq_multi_query_packed");
 }
 
 }  // extern "C"

@@ -44,8 +44,14 @@ struct QueryArgs {
     uint64_t *stamps;        // diagnostic builds only (CQ_STAMPS): per-phase cycle sums, else null
 };
 
+// ev_start | fast kernel | ev_mid | exact slow-path kernel | ev_stop  (events may be null)
 hipError_t launch_classify(const DevIndex &ix, QueryArgs a, int n_cus, hipStream_t stream,
-                           hipEvent_t ev_start, hipEvent_t ev_stop);
+                           hipEvent_t ev_start, hipEvent_t ev_mid, hipEvent_t ev_stop);
+
+// dst += src, element-wise, for a counter block (uint64) and an rcount array (uint32; may be null):
+// sums shards that ran on the SAME device (cq_multi rehearsal); distinct devices meet in RCCL.
+hipError_t launch_accumulate(uint64_t *dst64, const uint64_t *src64, uint64_t n64, uint32_t *dst32,
+                             const uint32_t *src32, uint64_t n32, hipStream_t stream);
 
 }  // namespace cq
 #endif

@@ -707,8 +707,27 @@ bool lds_hist_fits(uint32_t n_genomes)
 
 static uint32_t magic_of(uint32_t d) { return d == 0 ? 0u : (uint32_t)(((1u << 19) + d - 1) / d); }
 
+__global__ void __launch_bounds__(256) accumulate_kernel(uint64_t *dst64, const uint64_t *src64, uint64_t n64,
+                                                         uint32_t *dst32, const uint32_t *src32, uint64_t n32)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n64; i += stride) dst64[i] += src64[i];
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n32; i += stride) dst32[i] += src32[i];
+}
+
+hipError_t launch_accumulate(uint64_t *dst64, const uint64_t *src64, uint64_t n64, uint32_t *dst32,
+                             const uint32_t *src32, uint64_t n32, hipStream_t stream)
+{
+    const uint64_t n = n64 > n32 ? n64 : n32;
+    if (n == 0) return hipSuccess;
+    uint64_t grid = (n + 255) / 256;
+    if (grid > 256 * 16) grid = 256 * 16;
+    hipLaunchKernelGGL(accumulate_kernel, dim3((unsigned)grid), dim3(256), 0, stream, dst64, src64, n64, dst32, src32, n32);
+    return hipGetLastError();
+}
+
 hipError_t launch_classify(const DevIndex &ix, QueryArgs a, int n_cus, hipStream_t stream,
-                           hipEvent_t ev_start, hipEvent_t ev_stop)
+                           hipEvent_t ev_start, hipEvent_t ev_mid, hipEvent_t ev_stop)
 {
     a.use_lds_hist = lds_hist_fits(a.n_genomes) ? 1 : 0;
     a.pmax = a.wmax + (ix.hash_len - ix.minimizer_len);   // m-mer positions: max_len - m + 1
@@ -743,7 +762,7 @@ hipError_t launch_classify(const DevIndex &ix, QueryArgs a, int n_cus, hipStream
         if (grid == 0) grid = 1;
         if (ev_start) { e = hipEventRecord(ev_start, stream); if (e != hipSuccess) return e; }
         hipLaunchKernelGGL((classify_kernel<kFastR, kFastCAP, false>), dim3((unsigned)grid), dim3(kBlock), sm, stream, ix, a);
-        if (ev_stop) { e = hipEventRecord(ev_stop, stream); if (e != hipSuccess) return e; }
+        if (ev_mid) { e = hipEventRecord(ev_mid, stream); if (e != hipSuccess) return e; }
         e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
@@ -753,6 +772,8 @@ hipError_t launch_classify(const DevIndex &ix, QueryArgs a, int n_cus, hipStream
         const size_t sm = smem_bytes(kSlowR, kSlowCAP, a, a.use_lds_hist);
         hipLaunchKernelGGL((classify_kernel<kSlowR, kSlowCAP, true>), dim3((unsigned)(n_cus)), dim3(kBlock), sm, stream, ix, a);
         e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        if (ev_stop) e = hipEventRecord(ev_stop, stream);
     }
     return e;
 }

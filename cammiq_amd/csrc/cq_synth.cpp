@@ -19,6 +19,7 @@
 #include <atomic>
 #include <cstdint>
 #include <cstdio>
+#include <cmath>
 #include <cstring>
 #include <functional>
 #include <string>
@@ -272,18 +273,21 @@ int cqs_write_index(void *hh, const char *path_u, const char *path_d, uint64_t *
     return 0;
 }
 
-/* n reads of fixed length len into bases_out[n*len] (ASCII).  Deterministic per (seed, read index). */
-int cqs_make_reads(void *hh, uint64_t seed, uint64_t n, uint32_t len, double err, double frac_random,
-                   uint8_t *bases_out)
+/* Reads first .. first+n-1 of the stream `seed`, fixed length len, into bases_out[n*len] (ASCII).
+ * Deterministic per (seed, read index): any chunking of a stream gives the same reads.  Substitution
+ * errors are placed by geometric gaps (one draw per error, not one per base). */
+int cqs_make_reads_at(void *hh, uint64_t seed, uint64_t first, uint64_t n, uint32_t len, double err, double frac_random,
+                      uint8_t *bases_out)
 {
     World &w = *(World *)hh;
     const Params &p = w.p;
     if (len > p.genome_len) return -1;
     const unsigned chunks = 256;
+    const double inv_log_q = (err > 0 && err < 1) ? 1.0 / std::log1p(-err) : 0.0;
     thread_pool(chunks, [&](unsigned c) {
         uint64_t lo = n * c / chunks, hi = n * (c + 1) / chunks;
         for (uint64_t i = lo; i < hi; i++) {
-            Rng r(mix(seed, i));
+            Rng r(mix(seed, first + i));
             uint8_t *out = bases_out + i * len;
             if (r.unit() < frac_random) { fill_random(out, len, r); continue; }
             uint32_t g = (uint32_t)r.below(p.n_genomes);
@@ -291,12 +295,21 @@ int cqs_make_reads(void *hh, uint64_t seed, uint64_t n, uint32_t len, double err
             const uint8_t *G = w.genomes[g].data() + st;
             if (r.next() & 1) for (uint32_t j = 0; j < len; j++) out[j] = comp(G[len - 1 - j]);
             else memcpy(out, G, len);
-            if (err > 0)
-                for (uint32_t j = 0; j < len; j++)
-                    if (r.unit() < err) out[j] = (uint8_t)kAlpha[(sym(out[j]) + 1 + r.below(3)) & 3];
+            if (err >= 1) { for (uint32_t j = 0; j < len; j++) out[j] = (uint8_t)kAlpha[(sym(out[j]) + 1 + r.below(3)) & 3]; }
+            else if (err > 0)
+                for (double j = std::floor(std::log(1.0 - r.unit()) * inv_log_q); j < (double)len;
+                     j += 1.0 + std::floor(std::log(1.0 - r.unit()) * inv_log_q)) {
+                    const uint32_t q = (uint32_t)j;
+                    out[q] = (uint8_t)kAlpha[(sym(out[q]) + 1 + r.below(3)) & 3];
+                }
         }
     });
     return 0;
+}
+
+int cqs_make_reads(void *hh, uint64_t seed, uint64_t n, uint32_t len, double err, double frac_random, uint8_t *bases_out)
+{
+    return cqs_make_reads_at(hh, seed, 0, n, len, err, frac_random, bases_out);
 }
 
 }  // extern "C"

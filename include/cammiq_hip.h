@@ -19,6 +19,12 @@
  * on the calling thread is available from cq_last_error().  The library never aborts and
  * has NO CPU fallback for the classify step: without a usable HIP device cq_query*
  * fail with CQ_ERR_NO_DEVICE.
+ *
+ * Threading (as the reference: one caller, FqReader is not re-entrant): a handle carries ONE
+ * query at a time.  Its workspace -- slow-path list, kernel-timing events, SC pair map, staging
+ * buffers -- is shared by all calls on it, so do not overlap two cq_query* calls (or two
+ * cq_query_device launches on different streams) on the same handle; different handles are
+ * independent, and consecutive cq_query_device launches on ONE stream may be queued back to back.
  */
 #ifndef CAMMIQ_HIP_H_
 #define CAMMIQ_HIP_H_
@@ -30,7 +36,7 @@
 extern "C" {
 #endif
 
-#define CQ_ABI_VERSION 1
+#define CQ_ABI_VERSION 2
 
 typedef enum cq_status {
     CQ_OK = 0,
@@ -42,7 +48,8 @@ typedef enum cq_status {
     CQ_ERR_NO_DEVICE = -6, /* no HIP device / handle was loaded host-only */
     CQ_ERR_HIP = -7,       /* a HIP runtime call failed */
     CQ_ERR_NOMEM = -8,
-    CQ_ERR_LIMIT = -9      /* more than 2^31-1 leaves / nodes, key longer than 255, pair table full */
+    CQ_ERR_LIMIT = -9,     /* more than 2^31-1 leaves / nodes, key longer than 255, pair arrays too small */
+    CQ_ERR_COMM = -10      /* an RCCL call failed (multi-GPU entry points) */
 } cq_status;
 
 /* Which classify routine is restated. */
@@ -140,6 +147,22 @@ typedef struct cq_counts {
 int cq_query(cq_index *idx, int mode, const uint8_t *bases, const uint64_t *offsets,
              uint64_t n_reads, uint32_t n_genomes, cq_counts *out);
 
+/*
+ * Same call for reads the host has already packed with cq_pack_reads (packed + lens, row stride
+ * stride_words, longest read max_len): chunks are copied to the GPU on a copy stream while the
+ * previous chunk is being classified, counters come back at the end -- H2D + kernels + D2H, the
+ * bracket of the reference's "Time for query" (query.cpp:459,645-647) without the host-side
+ * packing.  Buffers from cq_host_alloc (pinned) make both directions run at link speed; pageable
+ * memory works too, slower.
+ */
+int cq_query_packed(cq_index *idx, int mode, const uint32_t *packed, const uint8_t *lens,
+                    uint64_t n_reads, uint32_t stride_words, uint32_t max_len, uint32_t n_genomes,
+                    cq_counts *out);
+
+/* Page-locked host memory for packed reads and for the rcount arrays of cq_counts. */
+int cq_host_alloc(void **p, size_t bytes);
+void cq_host_free(void *p);
+
 /* ---- packed / device-resident interface (multi-GPU hosts, benchmarks, pipelines) ---- */
 
 /* Words (uint32) per packed read for reads up to max_len bases; multiple of 4 (16-byte rows). */
@@ -155,7 +178,9 @@ int cq_pack_reads(const uint8_t *bases, const uint64_t *offsets, uint64_t n_read
                   uint32_t hash_len, uint32_t stride_words, uint32_t *packed, uint8_t *lens,
                   uint64_t *n_skipped);
 
-/* Number of uint64 in the device counter block for n_genomes: [cnt_u | cnt_d | nundet nconf nskipped flags]. */
+/* Number of uint64 in the device counter block for n_genomes:
+ * [cnt_u[G+1] | cnt_d[G+1] | nundet nconf nskipped flags nslow 0 0 0].  flags != 0: increments of the
+ * SC pair map were lost (map full).  Every word adds up across GPUs, flags included. */
 uint64_t cq_counter_words(uint32_t n_genomes);
 
 /*
@@ -171,13 +196,64 @@ int cq_query_device(cq_index *idx, int mode, const uint32_t *d_packed, const uin
                     uint64_t n_reads, uint32_t stride_words, uint32_t max_len, uint32_t n_genomes,
                     uint64_t *d_counters, uint32_t *d_rcount, void *stream);
 
-/* SC mode: copy out and clear the pair counters accumulated by cq_query_device. Synchronises. */
+/* SC mode: copy out and clear the pair counters accumulated by cq_query_device.  Synchronises.
+ * With pair_a == NULL only *n_pairs is written (nothing copied, nothing cleared); with arrays that
+ * are too small: CQ_ERR_LIMIT, *n_pairs = the number needed, nothing cleared -- call again. */
 int cq_pairs_fetch(cq_index *idx, uint32_t *pair_a, uint32_t *pair_b, uint64_t *pair_cnt,
                    uint64_t pair_cap, uint64_t *n_pairs);
 
-/* Duration in ms of the main classify kernel of the most recent cq_query_device call on this
- * handle (HIP events on the call's stream; synchronises on the stop event). */
+/* SC mode, device interface: size the pair map for at least n_slots slots (rounded up to a power of
+ * two; keep it under half full) and clear it.  cq_query / cq_query_packed / cq_multi_query grow the map
+ * by themselves and classify again when it fills up; cq_query_device cannot (it only reports
+ * flags != 0 in the counter block). */
+int cq_pairs_reserve(cq_index *idx, uint64_t n_slots);
+
+/* Duration in ms of the classify kernels of the most recent cq_query_device call on this handle
+ * (HIP events on the call's stream; synchronises on the last one): the main kernel and the exact
+ * slow-path kernel that re-classifies reads with more hits than the main kernel's lists hold.
+ * cq_last_kernel_ms = their sum. */
+int cq_last_kernel_times(cq_index *idx, float *fast_ms, float *slow_ms);
 int cq_last_kernel_ms(cq_index *idx, float *ms);
+
+/* ---- multi-GPU -----------------------------------------------------------------------------
+ * No reference analogue: the reference's one parallel axis is the OpenMP loop over reads
+ * (query.cpp:664-665).  Here that loop is cut into P contiguous shards, one per GPU, against an
+ * index replicated in every GPU's HBM; the outputs are commutative integer sums, so ONE RCCL
+ * all-reduce(sum) of the counter block (uint64) and of rcount (uint32) at the end of a query gives
+ * every GPU -- and the host, before it hands the counts to the ILP, query.cpp:251-258 -- exactly
+ * the single-GPU result.  Shard p of P takes reads [n*p/P, n*(p+1)/P). */
+int cq_shard_range(uint64_t n_reads, int rank, int n_ranks, uint64_t *lo, uint64_t *hi);
+
+/* (1) One process, several GPUs: one host thread per device inside the library. */
+typedef struct cq_multi cq_multi;
+
+/* Decode + lay out once, upload to every listed device, create the communicators
+ * (ncclCommInitAll).  A device may be listed more than once (rehearsal on a box with fewer GPUs
+ * than shards): shards on one device are summed by a kernel, distinct devices by RCCL. */
+int cq_multi_load(const char *path_u, const char *path_d, const int *devices, int n_dev, cq_multi **out);
+int cq_multi_size(const cq_multi *m);
+/* Borrowed handle of shard i (cq_index_get_info, cq_index_leaves, ...); owned by m. */
+cq_index *cq_multi_index(cq_multi *m, int i);
+/* cq_query / cq_query_packed over all devices of m; same arguments, same results. */
+int cq_multi_query(cq_multi *m, int mode, const uint8_t *bases, const uint64_t *offsets,
+                   uint64_t n_reads, uint32_t n_genomes, cq_counts *out);
+int cq_multi_query_packed(cq_multi *m, int mode, const uint32_t *packed, const uint8_t *lens,
+                          uint64_t n_reads, uint32_t stride_words, uint32_t max_len, uint32_t n_genomes,
+                          cq_counts *out);
+void cq_multi_free(cq_multi *m);
+
+/* (2) One process per GPU (torchrun / mpirun style): rank 0 makes an id, the launcher's own
+ * channel carries its CQ_COMM_ID_BYTES bytes to the other ranks, every rank joins with its
+ * handle's device (ncclCommInitRank), classifies its shard with cq_query_device and ends the
+ * query with cq_counts_allreduce (asynchronous on `stream`, in place). */
+#define CQ_COMM_ID_BYTES 128
+typedef struct cq_comm cq_comm;
+int cq_comm_unique_id(uint8_t *id);
+int cq_comm_init_rank(cq_index *idx, const uint8_t *id, int rank, int n_ranks, cq_comm **out);
+int cq_comm_info(const cq_comm *comm, int *rank, int *n_ranks);
+int cq_counts_allreduce(cq_comm *comm, uint64_t *d_counters, uint64_t n_counter_words,
+                        uint32_t *d_rcount, uint64_t n_rcount, void *stream);
+void cq_comm_free(cq_comm *comm);
 
 const char *cq_last_error(void);
 int cq_abi_version(void);

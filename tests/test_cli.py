@@ -59,11 +59,65 @@ def test_cli_quantification_mode_and_dump(tmp_path):
     e = g["exp"]["p"]
     assert f"Number of unlabeled reads: {e['nundet']}." in r.stderr
     assert f"Number of reads with conflict labels: {e['nconf']}." in r.stderr
+    assert "Loaded genome length file." in r.stderr
     rows = [l.split("\t") for l in dump.read_text().splitlines()]
+    assert rows[0] == ["#cammiq_counts", "2"]
+    assert rows[1][:2] == ["#query", "a.fq"] and int(rows[1][3]) == len(g["reads"])
+    assert int(rows[1][5]) == sum(len(x) for x in g["reads"])
     gl = [x for x in rows if x[0] == "G"]
     assert [int(x[3]) for x in gl] == e["cnt_u"][1:] and [int(x[4]) for x in gl] == e["cnt_d"][1:]
-    ru = {int(x[2]): int(x[6]) for x in rows if x[0] == "L" and x[1] == "u"}
+    # a13: glength / nus / nds of every genome, as the three text files next to index_u give them
+    meta = {k: dict(tuple(map(int, l.split())) for l in open(os.path.join(g["dir"], fn)))
+            for k, fn in (("gl", "genome_lengths.out"), ("nu", "unique_lmer_count_u.out"), ("nd", "unique_lmer_count_d.out"))}
+    for x in gl:
+        i = int(x[1])
+        assert (int(x[5]), int(x[6]), int(x[7])) == (meta["gl"][i], meta["nu"][i], meta["nd"].get(i, 0))
+    ru = {int(x[2]): int(x[8]) for x in rows if x[0] == "L" and x[1] == "u"}
     assert ru == {i: v for i, v in enumerate(e["rcount_u"]) if v}
+    rd = {int(x[2]): int(x[8]) for x in rows if x[0] == "L" and x[1] == "d"}
+    assert rd == {i: v for i, v in enumerate(e["rcount_d"]) if v}
+
+
+def _copy_fixture(g, dst, skip=()):
+    import shutil
+    for f in os.listdir(g["dir"]):
+        if f not in skip and f != "reads.txt.gz" and f != "expected.json":
+            shutil.copy(os.path.join(g["dir"], f), os.path.join(dst, f))
+    return os.path.join(dst, "index_u.bin1"), os.path.join(dst, "index_d.bin2")
+
+
+@pytest.mark.parametrize("missing,msg", [("genome_lengths.out", "Can not open genome length file."),
+                                         ("unique_lmer_count_u.out", "Can not open unique count file."),
+                                         ("unique_lmer_count_d.out", "Can not open doubly-unique count file.")])
+def test_cli_fails_like_the_reference_when_a_meta_file_is_missing(tmp_path, missing, msg):
+    """FqReader::loadGenomeLength (query.cpp:158-205) aborts when one of the three text files next to
+    index_u cannot be opened; the shell exits non-zero with the same message.  Runs without a GPU:
+    the index is loaded on the host first, the files are checked before any device work is needed."""
+    g = golden("survey_F1")
+    pu, pd = _copy_fixture(g, str(tmp_path), skip=(missing,))
+    fq = tmp_path / "q.fastq"
+    synth.write_fastq(str(fq), g["reads"][:10])
+    r = _run(["--query", "-f", str(tmp_path / "genome_map.out"), "-i", pu, pd, "-q", str(fq), "--device", "-1"])
+    assert r.returncode != 0 and msg in r.stderr, r.stderr
+
+
+def test_cli_meta_rules_follow_the_reference(tmp_path):
+    """--read_cnts with -Q does not read the meta files (query.cpp:303-331), with -q it does (:347);
+    a --unique index (no .bin2) may lack unique_lmer_count_d.out (never written, build.cpp:671-698)."""
+    g = golden("f_flat")    # unique-only fixture
+    pu, _ = _copy_fixture(g, str(tmp_path), skip=("unique_lmer_count_d.out",))
+    qd = tmp_path / "q"
+    qd.mkdir()
+    synth.write_fastq(str(qd / "reads.fastq"), g["reads"][:10])
+    common = ["--query", "-f", str(tmp_path / "genome_map.out"), "-i", pu, "--device", "-1"]
+    # host-only handle: everything up to the classify call runs, which then reports "no device"
+    r = _run(common + ["-q", str(qd / "reads.fastq")])
+    assert "Loaded genome length file." in r.stderr and "host-only" in r.stderr
+    os.remove(tmp_path / "unique_lmer_count_u.out")
+    r = _run(common + ["--read_cnts", "-Q", str(qd) + "/"])
+    assert "Can not open" not in r.stderr and "host-only" in r.stderr
+    r = _run(common + ["--read_cnts", "-q", str(qd / "reads.fastq")])
+    assert r.returncode != 0 and "Can not open unique count file." in r.stderr
 
 
 def _py_fastq_digest(path, min_l=0):

@@ -1,6 +1,9 @@
-"""N > 1 path on CPU: world_size-2 gloo.  Each rank classifies its shard (the oracle stands in
-for the GPU kernel here -- this is a test), the count vectors are all-reduced by the product's
-cammiq_amd.dist, and the result must equal the single-rank result exactly."""
+"""N > 1 path on CPU: world_size-2 gloo.  Each rank takes the shard the LIBRARY's rule gives it
+(cq_shard_range through the C ABI), classifies it (the oracle stands in for the GPU kernel here --
+this is a test), lays the result out as the device counter block, and the blocks are summed like
+cq_counts_allreduce sums them (gloo instead of RCCL: RCCL needs one GPU per rank).  The result must
+equal the single-rank result exactly, including the uint32 wrap of rcount and a flags word set on
+both ranks.  The RCCL path itself runs in tests/test_multi_gpu.py on the GPU box."""
 import os
 import socket
 import sys
@@ -41,6 +44,7 @@ def _worker(rank, world, port, out_dir):
     ctr[G + 1:2 * G + 2] = torch.from_numpy(r["cnt_d"].astype(np.int64))
     ctr[2 * G + 2] = r["nundet"]
     ctr[2 * G + 3] = r["nconf"]
+    ctr[2 * G + 5] = 1       # flags word set on BOTH ranks: the sum must still read "set" (!= 0)
     rc = torch.from_numpy(np.concatenate([r["rcount_u"], r["rcount_d"]]).view(np.int32).copy())
     if rank == 1:
         rc[0] += -5          # wrap-around check: int32 add must behave like the uint32 add
@@ -64,12 +68,13 @@ def test_two_rank_allreduce_equals_single_rank(tmp_path):
         rc = np.load(tmp_path / f"rc{rank}.npy").view(np.uint32)
         assert list(ctr[:G + 1]) == e["cnt_u"] and list(ctr[G + 1:2 * G + 2]) == e["cnt_d"]
         assert ctr[2 * G + 2] == e["nundet"] and ctr[2 * G + 3] == e["nconf"]
+        assert ctr[2 * G + 5] != 0
         assert list(rc) == e["rcount_u"] + e["rcount_d"]
 
 
 def test_shard_ranges_partition_the_reads():
     from cammiq_amd.dist import shard_range
-    for n in (0, 1, 7, 10_000_001):
+    for n in (0, 1, 7, 10_000_001, 2**63 + 12345):
         for world in (1, 2, 3, 8):
             cuts = [shard_range(n, r, world) for r in range(world)]
             assert cuts[0][0] == 0 and cuts[-1][1] == n

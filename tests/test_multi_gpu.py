@@ -1,0 +1,184 @@
+"""the multi-GPU path behind the C ABI (cq_multi_*, cq_comm_*, RCCL linked into
+libcammiq_hip.so).  The GPU box of this pool has ONE MI355X, so what runs here is
+  * n_dev = min(2, device count) distinct devices through ncclCommInitAll + ncclAllReduce (on a
+    one-GPU box: the one-rank communicator, same code path),
+  * two and three shards on the SAME device (the library sums shards that share a device with a
+    kernel and sends the per-device sums through RCCL) -- the sharding, the threads, the counter
+    layout and the SC pair merge with more than one shard,
+  * the one-process-per-GPU entry points (cq_comm_*) with world size 1.
+Every result must equal the single-handle result exactly."""
+import os
+
+import numpy as np
+import pytest
+
+import cammiq_amd as cq
+from cammiq_amd import synth
+import oracle_lib
+from util import assert_same, build_index, golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _n_devices():
+    import torch
+    return torch.cuda.device_count()
+
+
+@pytest.mark.parametrize("devices", ["distinct", [0, 0], [0, 0, 0]])
+def test_multi_query_equals_single_device(tmp_path, devices):
+    if devices == "distinct":
+        devices = list(range(min(2, _n_devices())))
+    gen = synth.clade_genomes(77, 4, 3, 4000, 0.03)
+    u, d = synth.select_markers(gen, 26, 40, keep_every=3, seed=7)
+    pu, pd = build_index(tmp_path, u, d, 26)
+    G = len(gen)
+    reads = synth.simulate_reads(gen, 30011, (26, 200), 0.01, 11, frac_random=0.1)
+    b, o = synth.concat_reads(reads)
+    one = cq.Index(pu, pd, device=0)
+    m = cq.Multi(pu, pd, devices)
+    assert m.size == len(devices) and m.n_leaves == one.n_leaves
+    ref = oracle_lib.OracleIndex(pu, pd).query(b, o, G, nthreads=8)
+    for mode in (cq.MODE_P, cq.MODE_SC):
+        want = one.query(b, o, G, mode=mode)
+        got = m.query(b, o, G, mode=mode)
+        assert_same(got, want, f"multi {devices} mode {mode}")
+        assert got["pairs"] == want["pairs"] and got["nskipped"] == want["nskipped"]
+    assert_same(m.query(b, o, G), ref, "multi vs oracle")
+    # pre-packed rows through the same shards
+    packed, lens, _ = cq.pack_reads(b, o, one.hash_len)
+    assert_same(m.query_packed(packed, lens, 200, G), ref, "multi packed")
+    # fewer reads than shards, and none at all
+    for k in (0, 1, len(devices)):
+        bb, oo = synth.concat_reads(reads[:k])
+        assert_same(m.query(bb, oo, G), one.query(bb, oo, G), f"{k} reads")
+    m.close()
+
+
+def test_query_packed_equals_query_and_kernel_times(tmp_path):
+    g = golden("f_deep")
+    b, o = synth.concat_reads(g["reads"])
+    ix = cq.Index(g["pu"], g["pd"], device=0)
+    packed, lens, sk = cq.pack_reads(b, o, ix.hash_len)
+    assert sk == 0
+    got = ix.query_packed(packed, lens, 255, g["G"])
+    assert_same(got, g["exp"]["p"], "packed, pageable")
+    # page-locked inputs and outputs (what bench.py's host-fed leg uses)
+    pp = cq.host_array(packed.size, np.uint32).reshape(packed.shape)
+    pl = cq.host_array(lens.size, np.uint8)
+    pp[:] = packed
+    pl[:] = lens
+    out = ix.counts_out(g["G"], pinned=True)
+    for _ in range(2):      # reused output arrays are overwritten
+        got = ix.query_packed(pp, pl, 255, g["G"], out=out)
+        assert_same(got, g["exp"]["p"], "packed, pinned")
+    fast, slow = ix.last_kernel_times()
+    assert fast > 0 and slow >= 0 and abs(ix.last_kernel_ms() - (fast + slow)) < 1e-3
+
+
+def test_large_rcount_comes_back_through_the_bounce_buffers(tmp_path):
+    """rcount arrays above 1 MiB in pageable memory take the pinned double-buffered D2H path."""
+    from cammiq_amd import bigsynth
+    w = bigsynth.World(seed=5, n_genomes=40, genome_len=1_200_000, pair_share=0.3)
+    pu, pd = str(tmp_path / "index_u.bin1"), str(tmp_path / "index_d.bin2")
+    nu, nd = w.write_index(pu, pd)
+    assert (nu + nd) * 4 > 5 * (1 << 20)
+    b, o = w.reads(seed=3, n=60000, length=100)
+    ix = cq.Index(pu, pd, device=0)
+    got = ix.query(b, o, 40)
+    ref = oracle_lib.OracleIndex(pu, pd).query(b, o, 40, nthreads=8)
+    assert_same(got, ref, "bounce")
+    packed, lens, _ = cq.pack_reads(b, o, 26)
+    assert_same(ix.query_packed(packed, lens, 100, 40, out=ix.counts_out(40, pinned=True)), ref, "pinned out")
+
+
+def test_pair_map_grows_instead_of_failing(tmp_path, monkeypatch):
+    """query64_sc's read_cnts_b with more distinct pairs than the device map has slots: the library
+    grows the map and classifies again (it used to return CQ_ERR_LIMIT); output arrays that are too
+    small are reported with the number needed and nothing is lost."""
+    rng = np.random.default_rng(3)
+    G = 60
+    keys_d, reads = {}, []
+    seen = set()
+    while len(keys_d) < 400:
+        k = bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), 12))
+        a, b_ = sorted(rng.choice(np.arange(1, G + 1), 2, replace=False))
+        if k in seen or synth.revcomp(k) in seen or (a, b_) in {(v[0], v[1]) for v in keys_d.values()}:
+            continue
+        seen.add(k)
+        keys_d[k] = (int(a), int(b_), 1, 1)
+        reads.append(b"GT" + k + b"GT")
+    pu, pd = build_index(tmp_path, {b"ACGTACGTACGTAA": (1, 1)}, keys_d, 10)
+    b, o = synth.concat_reads(reads * 3)
+    ref = oracle_lib.OracleIndex(pu, pd).query(b, o, G, mode=1)
+    assert len(ref["pairs"]) > 300
+    monkeypatch.setenv("CAMMIQ_PAIR_SLOTS", "16")      # start with a 16-slot map
+    ix = cq.Index(pu, pd, device=0)
+    got = ix.query(b, o, G, mode=cq.MODE_SC, pair_cap=1 << 12)
+    assert got["pairs"] == ref["pairs"]
+    assert_same(got, ref, "grown pair map", rcount=False)
+    with pytest.raises(cq.CammiqError) as e:            # arrays too small: told how many, nothing cleared
+        ix.query(b, o, G, mode=cq.MODE_SC, pair_cap=8)
+    assert e.value.code == -9
+    assert ix.count_pairs() == len(ref["pairs"])
+    assert ix.fetch_pairs(1 << 12) == ref["pairs"]
+    assert ix.count_pairs() == 0
+    m = cq.Multi(pu, pd, [0, 0])                        # and with shards: every shard's map grows, maps are merged
+    got = m.query(b, o, G, mode=cq.MODE_SC, pair_cap=1 << 12)
+    assert got["pairs"] == ref["pairs"]
+    assert_same(got, ref, "multi grown pair map", rcount=False)
+
+
+def test_comm_entry_points_world_size_one(tmp_path):
+    """cq_comm_unique_id / cq_comm_init_rank / cq_counts_allreduce with one rank: RCCL is initialised
+    and the collective runs on the caller's stream (the N > 1 case is the same calls on N processes)."""
+    import torch
+    g = golden("f_deep")
+    b, o = synth.concat_reads(g["reads"])
+    ix = cq.Index(g["pu"], g["pd"], device=0)
+    uid = cq.comm_unique_id()
+    assert len(uid) == 128
+    comm = cq.Comm(ix, uid, 0, 1)
+    packed, lens, _ = cq.pack_reads(b, o, ix.hash_len)
+    dp = torch.from_numpy(packed.view(np.int32)).cuda()
+    dl = torch.from_numpy(lens).cuda()
+    G = g["G"]
+    ctr = torch.zeros(ix.counter_words(G), dtype=torch.int64, device="cuda")
+    rc = torch.zeros(sum(ix.n_leaves), dtype=torch.int32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    lo, hi = cq.shard_range(len(lens), 0, 1)
+    assert (lo, hi) == (0, len(lens))
+    ix.query_device(cq.MODE_P, dp.data_ptr(), dl.data_ptr(), hi - lo, packed.shape[1], 255, G, ctr.data_ptr(),
+                    rc.data_ptr(), st)
+    comm.allreduce_counts(ctr.data_ptr(), ctr.numel(), rc.data_ptr(), rc.numel(), st)
+    torch.cuda.synchronize()
+    c = ctr.cpu().numpy().astype(np.uint64)
+    e = g["exp"]["p"]
+    assert list(c[:G + 1]) == e["cnt_u"] and list(c[G + 1:2 * G + 2]) == e["cnt_d"]
+    assert int(c[2 * G + 2]) == e["nundet"] and int(c[2 * G + 3]) == e["nconf"]
+    assert list(rc.cpu().numpy().view(np.uint32)) == e["rcount_u"] + e["rcount_d"]
+    comm.close()
+
+
+def test_cli_gpus_flag(tmp_path):
+    """`cammiq --query --gpus N` / `--devices a,b` (extensions): same TSV as one GPU.  --devices always
+    takes the cq_multi_* path, also with a repeated ordinal (two shards on the one GPU of this pool)."""
+    import subprocess
+    g = golden("survey_F1")
+    fq = tmp_path / "q1.fastq"
+    synth.write_fastq(str(fq), g["reads"])
+    cli = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cammiq_amd", "cammiq")
+    n = min(2, _n_devices())
+    out = tmp_path / "out.txt"
+    r = subprocess.run([cli, "--query", "--read_cnts", "-f", os.path.join(g["dir"], "genome_map.out"), "-i", g["pu"], g["pd"],
+                        "-q", str(fq), "-o", str(out), "--gpus", str(n)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert out.read_text() == "QUERY/TAXID\t1001\t1002\t1003\t1004\nq1.fastq\t412\t317\t404\t417\n"
+    out2 = tmp_path / "out2.txt"
+    r = subprocess.run([cli, "--query", "--read_cnts", "-f", os.path.join(g["dir"], "genome_map.out"), "-i", g["pu"], g["pd"],
+                        "-q", str(fq), "-o", str(out2), "--devices", "0,0"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert out2.read_text() == out.read_text() and "Number of unlabeled reads: 263." in r.stderr
+    r = subprocess.run([cli, "--query", "-f", os.path.join(g["dir"], "genome_map.out"), "-i", g["pu"], g["pd"],
+                        "-q", str(fq), "--gpus", "99"], capture_output=True, text=True)
+    assert r.returncode != 0 and "range [1, 64]" in r.stderr

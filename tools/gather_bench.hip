@@ -58,8 +58,24 @@ void run(const uint4 *tab, size_t bytes, uint32_t *out, int blocks_per_cu)
            bytes / 1048576.0, W, blocks_per_cu, n / ms / 1e6, n * W / ms / 1e6, n * 64 / ms / 1e6);
 }
 
-int main()
+// gather_bench            the round-1 sweep (2 MiB .. 8 GiB)
+// gather_bench MIB        one table size (MiB), W = 16 and 64 at 4 / 6 / 8 blocks per CU: the ceiling
+//                         bench.py's roofline.gather_ceiling_frac is measured against for that table
+int main(int argc, char **argv)
 {
+    if (argc > 1) {
+        const size_t bytes = (size_t)atoll(argv[1]) << 20;
+        uint4 *tab;
+        uint32_t *out;
+        CK(hipMalloc(&tab, bytes));
+        CK(hipMalloc(&out, 4));
+        CK(hipMemset(tab, 1, bytes));
+        for (int occ : {4, 6, 8}) {
+            run<16>(tab, bytes, out, occ);
+            run<64>(tab, bytes, out, occ);
+        }
+        return 0;
+    }
     size_t maxb = 8ull << 30;
     uint4 *tab;
     uint32_t *out;

@@ -1,21 +1,28 @@
 #!/bin/bash
-# tools/profile_round.sh  -- the rocprof evidence bench.py's roofline object cites (run on the GPU box):
-#   1. rocprofv3 --kernel-trace --stats of a default-length bench run      -> gpurun_out/prof/kernel_stats.csv
-#   2. rocprofv3 --pmc FETCH_SIZE, then --pmc WRITE_SIZE (separate passes) -> gpurun_out/prof/traffic.json
-# Copy the results into profiles/ afterwards (see profiles/README.md).
+# tools/profile_round.sh TAG [bench.py args...]  -- the rocprof evidence bench.py's roofline object cites
+# (run on the GPU box; TAG names the workload, e.g. "cfg2" for the default run, "cfg1" with `--config 1`):
+#   1. rocprofv3 --kernel-trace --stats of a bench run          -> gpurun_out/prof_TAG/kernel_stats.csv
+#   2. rocprofv3 --pmc FETCH_SIZE, then --pmc WRITE_SIZE (separate passes: FETCH_SIZE takes 3 of the 4 TCC
+#      slots, WRITE_SIZE 2 -- MI355X_MICROARCH.md "rocprofv3 PMC slots") -> gpurun_out/prof_TAG/traffic.json
+#   3. tools/gather_bench at the workload's table size          -> gpurun_out/prof_TAG/gather.txt
+# Copy the results into profiles/ afterwards (see profiles/README.md); tools/merge_traffic.py folds
+# traffic.json + gather.txt into profiles/traffic_r02.json under the workload's key.
 set -euo pipefail
 root="$(cd "$(dirname "$0")/.." && pwd)"
-out=$root/gpurun_out/prof
+tag=$1; shift
+out=$root/gpurun_out/prof_$tag
 rm -rf "$out"; mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -- python3 "$root/bench.py" --steps 10 --warmup 2 --no-cpu-baseline > "$out/bench_under_rocprof.json" 2> "$out/trace.err"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -- python3 "$root/bench.py" "$@" --steps 6 --warmup 2 --no-cpu-baseline --no-host-fed > "$out/bench_under_rocprof.json" 2> "$out/trace.err"
 cp "$(ls "$out"/trace/*/*kernel_stats.csv | head -1)" "$out/kernel_stats.csv"
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --output-format csv -d "$out/pmc_$c" -- python3 "$root/bench.py" --steps 2 --warmup 1 --no-cpu-baseline > "$out/bench_$c.json" 2> "$out/pmc_$c.err"
+  rocprofv3 --pmc $c --output-format csv -d "$out/pmc_$c" -- python3 "$root/bench.py" "$@" --steps 3 --warmup 1 --no-cpu-baseline --no-host-fed > "$out/bench_$c.json" 2> "$out/pmc_$c.err"
 done
 python3 - "$out" <<'PY'
 import csv,glob,json,sys,collections
 out=sys.argv[1]; res={}
+line=json.loads(open(out+"/bench_under_rocprof.json").read().strip().splitlines()[-1])
+cfg=line["config"]
 for c in ("FETCH_SIZE","WRITE_SIZE"):
     d=collections.defaultdict(float)
     for f in glob.glob(f"{out}/pmc_{c}/**/*counter_collection.csv",recursive=True):
@@ -24,7 +31,17 @@ for c in ("FETCH_SIZE","WRITE_SIZE"):
                 d[r["Dispatch_Id"]]+=float(r["Counter_Value"])
     v=list(d.values())
     res[c+"_KB_per_launch"]=sum(v)/len(v); res[c+"_launches"]=len(v)
-res["hbm_bytes_per_launch"]=(res["FETCH_SIZE_KB_per_launch"]+res["WRITE_SIZE_KB_per_launch"])*1024
+# gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE tallies a wide coalesced streaming read at half its
+# bytes.  The only such stream here is the packed rows (16 B per lane, read once): add the missing half.  The
+# rest of the kernel's reads are random 64-byte bucket / 16-byte node reads, calibrated at x1.0 in round 1
+# (profiles/r01_v1_traffic.json: 1.5e9 known bucket reads x 64 B).
+rows=cfg["reads_per_gpu"]*32+cfg["reads_per_gpu"]
+res["row_stream_bytes"]=rows
+res["hbm_bytes_per_launch"]=(res["FETCH_SIZE_KB_per_launch"]+res["WRITE_SIZE_KB_per_launch"])*1024+0.5*rows
+res["workload_key"]=cfg["workload_key"]; res["table_GB"]=cfg["table_GB"]
+res["kernel_ms_under_stats"]=line["roofline"]["kernel_ms"]
 json.dump(res,open(out+"/traffic.json","w"),indent=1); print(json.dumps(res))
 PY
-head -5 "$out/kernel_stats.csv"; cat "$out/bench_under_rocprof.json"
+mib=$(python3 -c "import json;print(int(json.load(open('$out/traffic.json'))['table_GB']*1e9/1048576))")
+"$root/tools/gather_bench" "$mib" > "$out/gather.txt" 2>&1 || true
+head -5 "$out/kernel_stats.csv"; cat "$out/bench_under_rocprof.json"; cat "$out/gather.txt"
