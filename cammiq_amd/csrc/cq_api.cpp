@@ -429,7 +429,7 @@ int cq_query_device(cq_index *ix, int mode, const uint32_t *d_packed, const uint
     if (!ix) return fail(CQ_ERR_ARG, "cq_query_device: NULL handle");
     if (ix->device < 0) return fail(CQ_ERR_NO_DEVICE, "index was loaded host-only (CQ_DEVICE_NONE); no CPU classify path exists");
     if (mode != CQ_MODE_P && mode != CQ_MODE_SC) return fail(CQ_ERR_ARG, "cq_query_device: unknown mode");
-    if (!d_counters || (n_reads && (!d_packed || !d_lens)) || stride_words == 0 || (stride_words & 3u) || stride_words > 16)
+    if (!d_counters || (n_reads && (!d_packed || !d_lens)) || stride_words == 0 || stride_words > 16)
         return fail(CQ_ERR_ARG, "cq_query_device: bad argument");
     if (n_reads > 0x7FFFFFFFull) return fail(CQ_ERR_ARG, "cq_query_device: more than 2^31-1 reads in one call");
     const cq::FlatImage &img = ix->H->img;
@@ -774,7 +774,7 @@ int cq_query_packed(cq_index *ix, int mode, const uint32_t *packed, const uint8_
                     uint32_t stride_words, uint32_t max_len, uint32_t n_genomes, cq_counts *out)
 {
     if (!ix || !out || (n_reads && (!packed || !lens))) return fail(CQ_ERR_ARG, "cq_query_packed: NULL argument");
-    if (stride_words == 0 || (stride_words & 3u) || stride_words > 16) return fail(CQ_ERR_ARG, "cq_query_packed: bad stride");
+    if (stride_words == 0 || stride_words > 16) return fail(CQ_ERR_ARG, "cq_query_packed: bad stride");
     int rc = query_checks(ix, mode, n_genomes, out, "cq_query_packed");
     if (rc != CQ_OK) return rc;
     Feed f;
@@ -1054,7 +1054,7 @@ int cq_multi_query_packed(cq_multi *m, int mode, const uint32_t *packed, const u
                           uint32_t stride_words, uint32_t max_len, uint32_t n_genomes, cq_counts *out)
 {
     if (!m || !out || (n_reads && (!packed || !lens))) return fail(CQ_ERR_ARG, "cq_multi_query_packed: NULL argument");
-    if (stride_words == 0 || (stride_words & 3u) || stride_words > 16) return fail(CQ_ERR_ARG, "cq_multi_query_packed: bad stride");
+    if (stride_words == 0 || stride_words > 16) return fail(CQ_ERR_ARG, "cq_multi_query_packed: bad stride");
     Feed f;
     f.packed = packed;
     f.lens = lens;

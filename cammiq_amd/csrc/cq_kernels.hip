@@ -69,12 +69,17 @@ constexpr int kWaves = kBlock / 64;
 #define CQ_WIN_PER_LANE 5  /* consecutive windows one lane probes per pass: 100-bp reads, 8 per wave -> 120 lanes' worth = two passes */
 #endif
 constexpr uint32_t kWinPerLane = CQ_WIN_PER_LANE;
+#ifndef CQ_RUN_SLOTS
+#define CQ_RUN_SLOTS (CQ_WIN_PER_LANE <= 6 ? 3 : 4)   /* minimizer runs per lane that get a bucket load; later runs go to the exact path */
+#endif
+constexpr uint32_t kRunSlots = CQ_RUN_SLOTS;
 #ifndef CQ_PRE_POS
 #define CQ_PRE_POS 8       /* adjacent m-mer positions one lane hashes in the pre-pass (<= 16) */
 #endif
 constexpr uint32_t kPrePos = CQ_PRE_POS;
 constexpr int kWorkDrain = CQ_WORK_DRAIN;     // drain a wave's list once it holds this many items
 constexpr int kWorkCap = kWorkDrain + 64;     // an iteration appends at most one item per lane
+constexpr uint32_t kNoBucket = 0xFFFFFFFFu;   // work item without a bucket: lookup_window recomputes it
 
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 
@@ -284,12 +289,18 @@ __device__ __forceinline__ void resolve_pair(const DevIndex &ix, const Tile &t, 
 // chain, then trie walk + hit append for every table that holds the h-mer.  Runs only for
 // the few windows the probe loop flagged, one window per lane, all lanes busy.
 template <int CAP>
-__device__ __forceinline__ void lookup_window(const DevIndex &ix, const Tile &t, uint32_t swp, uint32_t rl,
+__device__ __forceinline__ void lookup_window(const DevIndex &ix, const Tile &t, uint32_t swp, uint32_t pmax, uint32_t rl,
                                               uint32_t pw, uint32_t b)
 {
     const uint32_t h = ix.hash_len;
     const uint32_t *row = t.rows + rl * swp;
     const uint32_t len = t.len[rl];
+    if (b == kNoBucket) {   // the probe loop kept no bucket for this window (fourth minimizer of its lane): look it up again
+        const uint32_t *ph = t.phi + rl * pmax + pw;
+        uint32_t v = ph[0];
+        for (uint32_t i = 1; i + ix.minimizer_len <= h; i++) v = min(v, ph[i]);
+        b = cq_bucket_of_minimizer(v, ix.n_buckets);
+    }
     // forward h-mer = bit-field of the row; reverse complement = ~bitreverse
     const uint32_t q = pw >> 4, s = (pw & 15u) * 2u;
     const uint64_t x = ((uint64_t)row[q] << 32) | row[q + 1];
@@ -309,12 +320,12 @@ __device__ __forceinline__ void lookup_window(const DevIndex &ix, const Tile &t,
 
 // Drain this wave's work list (n <= kWorkCap items: .x = bucket, .y = read | window << 8).
 template <int CAP>
-__device__ __forceinline__ void drain_work(const DevIndex &ix, const Tile &t, uint32_t swp, uint32_t n)
+__device__ __forceinline__ void drain_work(const DevIndex &ix, const Tile &t, uint32_t swp, uint32_t pmax, uint32_t n)
 {
     wave_sync();
     for (uint32_t i = lane_id(); i < n; i += 64) {
         const uint2 it = t.work[i];
-        lookup_window<CAP>(ix, t, swp, it.y & 255u, it.y >> 8, it.x);
+        lookup_window<CAP>(ix, t, swp, pmax, it.y & 255u, it.y >> 8, it.x);
     }
     wave_sync();
 }
@@ -421,7 +432,7 @@ template <int R, int CAP, bool SLOW>
 __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(CQ_WAVES_PER_EU, CQ_WAVES_PER_EU)))
 classify_kernel(DevIndex ix, QueryArgs a)
 {
-    static_assert(SLOW || R * 4 <= 64, "a sub-tile's rows must fit one 16-byte load per lane");
+    static_assert(SLOW || R * 4 <= 64, "a sub-tile's rows (R x <= 16 words) must fit one 16-byte load per lane");
     extern __shared__ __align__(16) uint32_t smem[];
     const uint32_t sw = a.stride_words, swp = sw + 2;
     const uint32_t G1 = a.n_genomes + 1;
@@ -459,15 +470,23 @@ classify_kernel(DevIndex ix, QueryArgs a)
         if (sub >= n_sub) return;
         const uint64_t r0 = sub * R;
         const uint32_t nr = (uint32_t)((n_reads - r0) < (uint64_t)R ? (n_reads - r0) : (uint64_t)R);
+        // the sub-tile's rows are nr * sw consecutive words (any stride 1..16: rows are not padded to 16 bytes,
+        // they travel over PCIe); lane l takes words 4l .. 4l+3, the last lane of a ragged tail word by word
+        const uint32_t nwords = nr * sw, w0 = lane * 4;
+        const uint32_t *src = a.packed + r0 * sw + w0;
+        if (w0 + 4 <= nwords) {
 #if CQ_NT_ROWS
-        if (lane < nr * (sw >> 2)) {
-            const uint32_t *src = a.packed + r0 * sw + lane * 4;
             pf_row = make_uint4(__builtin_nontemporal_load(src), __builtin_nontemporal_load(src + 1),
                                 __builtin_nontemporal_load(src + 2), __builtin_nontemporal_load(src + 3));
-        }
 #else
-        if (lane < nr * (sw >> 2)) pf_row = ((const uint4 *)(a.packed + r0 * sw))[lane];
+            pf_row = make_uint4(src[0], src[1], src[2], src[3]);
 #endif
+        } else if (w0 < nwords) {
+            pf_row.x = src[0];
+            pf_row.y = w0 + 1 < nwords ? src[1] : 0u;
+            pf_row.z = w0 + 2 < nwords ? src[2] : 0u;
+            pf_row.w = 0u;
+        }
         if (lane < nr) pf_len = a.lens[r0 + lane];
     };
     if (!SLOW) prefetch(wave_gid);
@@ -482,11 +501,21 @@ classify_kernel(DevIndex ix, QueryArgs a)
         // ---- stage the sub-tile: 2-bit rows -> LDS.  The fast path fetched them one sub-tile
         // ahead (16 B per lane, contiguous: R reads x <= 4 vectors fit one wave instruction).
         if (!SLOW) {
-            const uint32_t nvec = nr * (sw >> 2);
-            if (lane < nvec) {
-                const uint32_t w = lane * 4, rl = div_small(w, sw, a.magic_s), c = w - __umul24(rl, sw);
-                uint32_t *dst = t.rows + rl * swp + c;
-                dst[0] = pf_row.x; dst[1] = pf_row.y; dst[2] = pf_row.z; dst[3] = pf_row.w;
+            const uint32_t nwords = nr * sw, w = lane * 4;
+            if (w < nwords) {
+                if ((sw & 3u) == 0) {   // a 16-byte piece lies inside one row
+                    const uint32_t rl = div_small(w, sw, a.magic_s), c = w - __umul24(rl, sw);
+                    uint32_t *dst = t.rows + rl * swp + c;
+                    dst[0] = pf_row.x; dst[1] = pf_row.y; dst[2] = pf_row.z; dst[3] = pf_row.w;
+                } else {                // word by word: row r starts at word r * sw of the piece stream
+                    const uint32_t v[4] = {pf_row.x, pf_row.y, pf_row.z, pf_row.w};
+#pragma unroll
+                    for (uint32_t i = 0; i < 4; i++)
+                        if (w + i < nwords) {
+                            const uint32_t rl = div_small(w + i, sw, a.magic_s), c = w + i - __umul24(rl, sw);
+                            t.rows[rl * swp + c] = v[i];
+                        }
+                }
             }
         } else {
             for (uint32_t i = lane; i < nr * sw; i += 64) {
@@ -543,6 +572,8 @@ classify_kernel(DevIndex ix, QueryArgs a)
         // prefix popcount, the list length is wave-uniform and lives in a register -- and gets
         // the exact treatment (lookup_window) once 64 of them are waiting.
         constexpr uint32_t KW = kWinPerLane;
+        constexpr uint32_t NS = kRunSlots;                      // bucket slots (minimizer runs) a lane keeps per pass
+        static_assert(32u + 2u * (KW - 1u) <= 64u && KW <= 32u, "a lane's windows must fit one 64-bit piece of the row");
         const uint32_t gpr = (wmax + KW - 1u) / KW;             // window groups per read
         const uint32_t total = nr * gpr;
         const uint32_t hmask = h < 16 ? (0xFFFFFFFFu >> (32u - 2u * h)) : 0xFFFFFFFFu;   // keys shorter than 32 bits
@@ -551,9 +582,13 @@ classify_kernel(DevIndex ix, QueryArgs a)
             const uint32_t idx = base + lane;
             bool act = idx < total;
             uint32_t rl = 0, pw0 = 0, len = 0, fl = 0;
-            uint32_t bk[KW];
+            // A lane's KW consecutive windows fall into RUNS of equal minimizer; run r (r < NS) gets bucket slot r.
+            // bnd[r] = first window of run r (r >= 1; >= KW when the lane has no such run), bkt[r] = its bucket.
+            uint32_t bnd[NS + 1], bkt[NS];
 #pragma unroll
-            for (uint32_t k = 0; k < KW; k++) bk[k] = 0;
+            for (uint32_t r = 0; r <= NS; r++) bnd[r] = KW;
+#pragma unroll
+            for (uint32_t r = 0; r < NS; r++) bkt[r] = 0;
             if (act) {
                 rl = div_small(idx, gpr, a.magic_w);
                 pw0 = (idx - __umul24(rl, gpr)) * KW;
@@ -585,6 +620,22 @@ classify_kernel(DevIndex ix, QueryArgs a)
                     mp[2 % KW] = min(s2, p12);
                     mp[3 % KW] = min(s3, p13);
                     mp[4 % KW] = min(core, min(p13, v14));
+                } else if (nphi == 11 && KW <= 11) {
+                    // every window contains m-mer 10: window k = min(suffix minimum of v[k..10], prefix minimum of v[10..k+10])
+                    uint32_t v[KW + 10];
+#pragma unroll
+                    for (uint32_t i = 0; i < KW + 10; i++) v[i] = ph[i];
+                    uint32_t suf[11];
+                    suf[10] = v[10];
+#pragma unroll
+                    for (int i = 9; i >= 0; i--) suf[i] = min(v[i], suf[i + 1]);
+                    uint32_t pre = v[10];
+                    mp[0] = suf[0];
+#pragma unroll
+                    for (uint32_t k = 1; k < KW; k++) {
+                        pre = min(pre, v[k + 10]);
+                        mp[k] = min(suf[k < 11 ? k : 10], pre);
+                    }
                 } else {
 #pragma unroll
                     for (uint32_t k = 0; k < KW; k++) {
@@ -593,16 +644,35 @@ classify_kernel(DevIndex ix, QueryArgs a)
                         mp[k] = v;
                     }
                 }
-                // buckets: key_lo[4] is the only bucket read of the hot loop; a window whose
-                // minimizer equals its left neighbour's reuses that neighbour's registers
-                uint4 kl[KW];
-                bk[0] = cq_bucket_of_minimizer(mp[0], ix.n_buckets);
-                kl[0] = ix.slots[(size_t)bk[0] * 4];
+                // run boundaries: bit k of cm = window k starts a new run
+                uint32_t cm = 0;
 #pragma unroll
-                for (uint32_t k = 1; k < KW; k++) {
-                    bk[k] = cq_bucket_of_minimizer(mp[k], ix.n_buckets);
-                    kl[k] = kl[k - 1];
-                    if (k < nwin && mp[k] != mp[k - 1]) kl[k] = ix.slots[(size_t)bk[k] * 4];
+                for (uint32_t k = 1; k < KW; k++) cm |= ((k < nwin) && (mp[k] != mp[k - 1])) ? (1u << k) : 0u;
+                uint32_t mr[NS];
+                mr[0] = mp[0];
+#pragma unroll
+                for (uint32_t r = 1; r <= NS; r++) {
+                    bnd[r] = cm ? (uint32_t)__ffs(cm) - 1u : KW;
+                    cm &= cm - 1u;
+                    if (r < NS) {
+                        mr[r] = 0;
+#pragma unroll
+                        for (uint32_t k = 1; k < KW; k++) mr[r] = (bnd[r] == k) ? mp[k] : mr[r];
+                    }
+                }
+                // buckets: key_lo[4] is the only bucket read of the hot loop -- ONE 16-byte load per minimizer run,
+                // all of a lane's loads issued back to back and waited for once (no loaded value is copied or
+                // selected before the last load has been issued: a dependent use would put a wait between them)
+                uint4 kk[NS];
+                bkt[0] = cq_bucket_of_minimizer(mr[0], ix.n_buckets);
+#pragma unroll
+                for (uint32_t r = 1; r < NS; r++)
+                    if (bnd[r] < KW) bkt[r] = cq_bucket_of_minimizer(mr[r], ix.n_buckets);
+                kk[0] = ix.slots[(size_t)bkt[0] * 4];
+#pragma unroll
+                for (uint32_t r = 1; r < NS; r++) {
+                    kk[r] = make_uint4(0xFFFFFFFEu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);   // never selected unless loaded
+                    if (bnd[r] < KW) kk[r] = ix.slots[(size_t)bkt[r] * 4];
                 }
                 // low words.  Forward h-mer: the 32 bits that END at the window's end -- all KW of them
                 // inside the 64 bits that end at the last window's end.  Reverse complement: ~reverse of
@@ -616,10 +686,19 @@ classify_kernel(DevIndex ix, QueryArgs a)
                 for (uint32_t k = 0; k < KW; k++) {
                     const uint32_t flo = (uint32_t)(t64 >> (2u * (KW - 1u - k))) & hmask;
                     const uint32_t rlo = (uint32_t)(rh64 >> (2u * k)) & hmask;
+                    uint4 kl = kk[0];
+                    if (k >= 1) {
+#pragma unroll
+                        for (uint32_t r = 1; r < NS; r++) {
+                            const bool in = k >= bnd[r];
+                            kl.x = in ? kk[r].x : kl.x; kl.y = in ? kk[r].y : kl.y;
+                            kl.z = in ? kk[r].z : kl.z; kl.w = in ? kk[r].w : kl.w;
+                        }
+                    }
                     // slot 0's bit 0 is the overflow flag: compare it without that bit
-                    const bool f = ((kl[k].x ^ flo) < 2u) | (kl[k].y == flo) | (kl[k].z == flo) | (kl[k].w == flo) |
-                                   ((kl[k].x ^ rlo) < 2u) | (kl[k].y == rlo) | (kl[k].z == rlo) | (kl[k].w == rlo) |
-                                   ((kl[k].x & 1u) != 0);
+                    const bool f = ((kl.x ^ flo) < 2u) | (kl.y == flo) | (kl.z == flo) | (kl.w == flo) |
+                                   ((kl.x ^ rlo) < 2u) | (kl.y == rlo) | (kl.z == rlo) | (kl.w == rlo) |
+                                   ((kl.x & 1u) != 0) | (k >= bnd[NS]);   // run without a slot: no bucket was loaded, the exact path decides
                     if (f && k < nwin) fl |= 1u << k;
                 }
             }
@@ -632,19 +711,20 @@ classify_kernel(DevIndex ix, QueryArgs a)
                 if (has) {
                     const uint32_t k = (uint32_t)__ffs(fl) - 1u;
                     fl &= fl - 1u;
-                    uint32_t b = bk[0];
+                    uint32_t b = bkt[0];
 #pragma unroll
-                    for (uint32_t j = 1; j < KW; j++) b = (k == j) ? bk[j] : b;
+                    for (uint32_t r = 1; r < NS; r++) b = (k >= bnd[r]) ? bkt[r] : b;
+                    b = (k >= bnd[NS]) ? kNoBucket : b;
                     const uint32_t off = nw + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
                                                                         __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
                     t.work[off] = make_uint2(b, rl | ((pw0 + k) << 8));
                 }
                 nw += (uint32_t)__popcll(mask);
-                if (nw >= (uint32_t)kWorkDrain) { CQ_STAMP(2); if (CQ_EXP != 1) drain_work<CAP>(ix, t, swp, nw); nw = 0; CQ_STAMP(3); }
+                if (nw >= (uint32_t)kWorkDrain) { CQ_STAMP(2); if (CQ_EXP != 1) drain_work<CAP>(ix, t, swp, pmax, nw); nw = 0; CQ_STAMP(3); }
             }
         }
         CQ_STAMP(2);   // probe loop
-        if (nw && CQ_EXP != 1) drain_work<CAP>(ix, t, swp, nw);
+        if (nw && CQ_EXP != 1) drain_work<CAP>(ix, t, swp, pmax, nw);
         CQ_STAMP(3);   // exact lookups
         wave_sync();
 

@@ -5,8 +5,8 @@
 // bytes through symbolIdx on every access (query.cpp:1860-1873).  Here the mapping happens
 // once: base j of a read lands in word j/16 at bits [31-2(j%16) : 30-2(j%16)], so an h-mer
 // starting at base p is a big-endian bit-field of the row and the kernel extracts it with
-// two shifts.  Rows have a fixed stride (multiple of 16 bytes) so a tile of reads is one
-// contiguous, coalesced load.
+// two shifts.  Rows have a fixed stride of 1..16 words (ceil(longest read / 16), no padding: the
+// rows are what travels over PCIe), so a tile of reads is one contiguous, coalesced load.
 #include <algorithm>
 #include <atomic>
 #include <cstring>
@@ -113,10 +113,10 @@ void pack_range(const uint8_t *bases, const uint64_t *offsets, uint64_t lo, uint
 
 extern "C" uint32_t cq_pack_stride_words(uint32_t max_len)
 {
+    // 16 bases per word, no padding to 16 bytes: rows are what travels over PCIe (100 bp: 28 bytes, not 32)
     if (max_len > 255) max_len = 255;
-    uint32_t w = (max_len + 15) / 16;
-    w = (w + 3) & ~3u;
-    return w ? w : 4;
+    const uint32_t w = (max_len + 15) / 16;
+    return w ? w : 1;
 }
 
 extern "C" int cq_pack_reads(const uint8_t *bases, const uint64_t *offsets, uint64_t n_reads,
@@ -124,7 +124,7 @@ extern "C" int cq_pack_reads(const uint8_t *bases, const uint64_t *offsets, uint
                              uint64_t *n_skipped)
 {
     if ((!bases && n_reads && offsets && offsets[n_reads] != 0) || !offsets || !packed || !lens ||
-        stride_words == 0 || (stride_words & 3u))
+        stride_words == 0 || stride_words > 16)
         return CQ_ERR_ARG;
     unsigned hw = std::thread::hardware_concurrency();
     unsigned nt = std::max(1u, std::min(hw ? hw : 1u, 32u));

@@ -165,7 +165,8 @@ void cq_host_free(void *p);
 
 /* ---- packed / device-resident interface (multi-GPU hosts, benchmarks, pipelines) ---- */
 
-/* Words (uint32) per packed read for reads up to max_len bases; multiple of 4 (16-byte rows). */
+/* Words (uint32) per packed read for reads up to max_len bases: ceil(max_len / 16), 1..16.  Any stride in
+ * that range that holds the longest read is accepted by the calls below (rows are not padded to 16 bytes). */
 uint32_t cq_pack_stride_words(uint32_t max_len);
 
 /*

@@ -40,7 +40,7 @@ int main(int argc, char **argv)
         if (cq_query(ix, CQ_MODE_SC, read, offs, 1, 4, &c) != CQ_ERR_NO_DEVICE) return 11;
     }
     offs[0] = 0; offs[1] = 32;
-    if (cq_pack_stride_words(32) != 4) return 12;
+    if (cq_pack_stride_words(32) != 2 || cq_pack_stride_words(100) != 7) return 12;
     if (cq_pack_reads(read, offs, 1, info.hash_len, 4, packed, &len, &skipped) != CQ_OK) return 13;
     if (len != 32 || skipped != 0 || packed[0] != 0x1B1B1B1Bu) return 14;   /* ACGT = 00 01 10 11, MSB first */
     printf("ok hash_len %u leaves %llu+%llu keys %llu\n", info.hash_len, (unsigned long long)info.n_leaves[0],

@@ -1,3 +1,5 @@
+import torch  # noqa: F401  (FIRST: torch bundles its own HIP/HSA runtime under un-versioned NEEDED names; loaded after
+#                       libcammiq_hip.so pulled in /opt/rocm's copies, a second runtime would come up and see no GPU)
 import os
 import sys
 

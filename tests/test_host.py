@@ -156,8 +156,8 @@ def test_packer():
         # bits past the end are zero
         full = int.from_bytes(packed[r].astype(">u4").tobytes(), "big")
         assert full & ((1 << (16 * 32 - 2 * len(read))) - 1) == 0
-    assert cq.stride_words(100) == 8 and cq.stride_words(150) == 12 and cq.stride_words(255) == 16
-    assert cq.stride_words(1) == 4 and cq.stride_words(64) == 4 and cq.stride_words(65) == 8
+    assert cq.stride_words(100) == 7 and cq.stride_words(150) == 10 and cq.stride_words(255) == 16
+    assert cq.stride_words(1) == 1 and cq.stride_words(64) == 4 and cq.stride_words(65) == 5 and cq.stride_words(0) == 1
 
 
 def test_packer_large_multithreaded():
@@ -168,7 +168,7 @@ def test_packer_large_multithreaded():
     packed, lens, sk = cq.pack_reads(bases, offs, 26)
     assert sk == 0 and (lens == L).all()
     sym = np.searchsorted(np.frombuffer(b"ACGT", np.uint8), bases).reshape(n, L).astype(np.uint32)
-    want = np.zeros((n, 8), np.uint32)
+    want = np.zeros((n, cq.stride_words(L)), np.uint32)
     for j in range(L):
         want[:, j >> 4] |= sym[:, j] << np.uint32(30 - 2 * (j & 15))
     assert np.array_equal(packed, want)

@@ -77,19 +77,21 @@ def test_query_packed_equals_query_and_kernel_times(tmp_path):
 
 
 def test_large_rcount_comes_back_through_the_bounce_buffers(tmp_path):
-    """rcount arrays above 1 MiB in pageable memory take the pinned double-buffered D2H path."""
+    """rcount arrays in pageable memory take the pinned double-buffered D2H path: rcount_u here is larger
+    than one 16 MiB bounce buffer (several pieces), rcount_d larger than the 1 MiB direct-copy limit."""
     from cammiq_amd import bigsynth
-    w = bigsynth.World(seed=5, n_genomes=40, genome_len=1_200_000, pair_share=0.3)
+    G = 200
+    w = bigsynth.World(seed=5, n_genomes=G, genome_len=1_200_000, pair_share=0.3)
     pu, pd = str(tmp_path / "index_u.bin1"), str(tmp_path / "index_d.bin2")
     nu, nd = w.write_index(pu, pd)
-    assert (nu + nd) * 4 > 5 * (1 << 20)
+    assert nu * 4 > (16 << 20) and nd * 4 > (1 << 20)
     b, o = w.reads(seed=3, n=60000, length=100)
     ix = cq.Index(pu, pd, device=0)
-    got = ix.query(b, o, 40)
-    ref = oracle_lib.OracleIndex(pu, pd).query(b, o, 40, nthreads=8)
+    got = ix.query(b, o, G)
+    ref = oracle_lib.OracleIndex(pu, pd).query(b, o, G, nthreads=8)
     assert_same(got, ref, "bounce")
     packed, lens, _ = cq.pack_reads(b, o, 26)
-    assert_same(ix.query_packed(packed, lens, 100, 40, out=ix.counts_out(40, pinned=True)), ref, "pinned out")
+    assert_same(ix.query_packed(packed, lens, 100, G, out=ix.counts_out(G, pinned=True)), ref, "pinned out")
 
 
 def test_pair_map_grows_instead_of_failing(tmp_path, monkeypatch):

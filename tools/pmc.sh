@@ -1,13 +1,14 @@
 #!/bin/bash
 # tools/pmc.sh TAG COUNTER...   one rocprofv3 --pmc pass of a short bench run; prints per-launch means
 # of the fast classify kernel.  (Counters only: never combined with sys/hip/hsa tracing.)
-set -euo pipefail
+# BENCH_ARGS="--config 1" selects the workload (default: bench.py's own default, configs[2]).
+set -uo pipefail
 root="$(cd "$(dirname "$0")/.." && pwd)"
 tag=$1; shift
 out=$root/gpurun_out/pmc_$tag
 rm -rf "$out"; mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --pmc "$@" --output-format csv -d "$out" -- python3 "$root/bench.py" --steps 2 --warmup 1 --no-cpu-baseline > "$out/bench.json" 2> "$out/err.log" || { tail -20 "$out/err.log"; exit 1; }
+rocprofv3 --pmc "$@" --output-format csv -d "$out" -- python3 "$root/bench.py" ${BENCH_ARGS:-} --steps 2 --warmup 1 --no-cpu-baseline --no-host-fed > "$out/bench.json" 2> "$out/err.log" || { echo "pass $tag ($*) failed:"; tail -5 "$out/err.log"; exit 0; }
 python3 - "$out" <<'PY'
 import csv,glob,sys,collections
 out=sys.argv[1]
@@ -20,5 +21,5 @@ for k,v in sorted(acc.items()):
     d=collections.defaultdict(float)
     for i,x in v: d[i]+=x
     vals=list(d.values())
-    print(f"{k:28s} launches {len(vals)}  mean/launch {sum(vals)/len(vals):.4g}")
+    print(f"{k:32s} launches {len(vals)}  mean/launch {sum(vals)/len(vals):.4g}")
 PY
