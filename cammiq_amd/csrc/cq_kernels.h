@@ -23,6 +23,7 @@ struct QueryArgs {
     const uint32_t *packed;  // n_reads rows of stride_words uint32
     const uint8_t *lens;
     uint64_t n_reads;
+    uint64_t read0;          // index of packed[0] within the call's rows (set by the launcher when it cuts a call into launches)
     uint32_t stride_words;
     uint32_t wmax;           // max windows per read in this batch: max_len - h + 1
     uint32_t pmax;           // max m-mer positions per read: max_len - m + 1   (set by the launcher)

@@ -60,7 +60,7 @@ constexpr int kWaves = kBlock / 64;
 #define CQ_NT_ROWS 1   /* read rows are a read-once stream: nontemporal loads keep them from displacing buckets in L2 */
 #endif
 #ifndef CQ_EXP
-#define CQ_EXP 0   /* diagnostic builds only (wrong results): 1 no exact lookups, 2 no bucket chains, 3 no decision, 4 lookups stop after the first bucket, 5 no rcount atomics, 6 hits resolved but not recorded */
+#define CQ_EXP 0   /* diagnostic builds only (wrong results): 1 no exact lookups, 2 no bucket chains, 3 no decision, 4 lookups stop after the first bucket, 5 no rcount atomics, 6 hits resolved but not recorded, 8 no bucket loads / compares in the probe loop, 9 no probe loop at all, 10 no pre-pass hashing */
 #endif
 #ifndef CQ_MAX_BLOCKS_PER_CU
 #define CQ_MAX_BLOCKS_PER_CU 6
@@ -152,7 +152,7 @@ __host__ __device__ inline SmemLayout smem_layout(int R, int CAP, uint32_t sw, u
     L.per_wave = o;
     o *= kWaves;
     L.scal = o;    o += 4;
-    L.hist = o;    if (hist) o += 2u * (n_genomes + 1u);
+    L.hist = o;    if (hist) o += n_genomes + 1u;       // one word per genome: cnt_u in the low half, cnt_d in the high half
     L.total = o;
     return L;
 }
@@ -167,7 +167,7 @@ struct Tile {             // one wave's view of LDS
     uint32_t *hit_r2;    // [R][CAP]
     uint32_t *nwork;     // [1]        length of this wave's work list
     uint2 *work;         // [kWorkCap] .x = trie code, .y = read | strand<<8 | pos<<9
-    uint32_t *hist;      // [2*(G+1)] or null     (workgroup-shared)
+    uint32_t *hist;      // [G+1] or null: cnt_u | cnt_d << 16 (workgroup-shared; see kMaxReadsPerGroup)
     uint32_t *scal;      // [4] nundet nconf nskipped nslow   (workgroup-shared)
 };
 
@@ -334,9 +334,8 @@ __device__ __forceinline__ void add_cnt(const QueryArgs &a, const Tile &t, uint3
 {
     // which: 0 = cnt_u, 1 = cnt_d
     if (rid > a.n_genomes) return;  // guarded on the host (CQ_ERR_RANGE); never index out of bounds
-    uint32_t i = which * (a.n_genomes + 1) + rid;
-    if (t.hist) atomicAdd(&t.hist[i], 1u);
-    else atomicAdd((unsigned long long *)&a.counters[i], 1ull);
+    if (t.hist) atomicAdd(&t.hist[rid], which ? 0x10000u : 1u);
+    else atomicAdd((unsigned long long *)&a.counters[which * (a.n_genomes + 1) + rid], 1ull);
 }
 
 __device__ __forceinline__ void pair_add(const QueryArgs &a, uint32_t pa, uint32_t pb)
@@ -455,7 +454,7 @@ classify_kernel(DevIndex ix, QueryArgs a)
     t.hist = a.use_lds_hist ? smem + L.hist : nullptr;
 
     if (tid < 4) t.scal[tid] = 0;
-    if (t.hist) for (uint32_t i = tid; i < 2 * G1; i += kBlock) t.hist[i] = 0;
+    if (t.hist) for (uint32_t i = tid; i < G1; i += kBlock) t.hist[i] = 0;
     __syncthreads();   // the only workgroup barrier before the final flush
 
     uint64_t n_reads = a.n_reads;
@@ -468,7 +467,7 @@ classify_kernel(DevIndex ix, QueryArgs a)
     uint32_t pf_len = 0;
     auto prefetch = [&](uint64_t sub) {
         if (sub >= n_sub) return;
-        const uint64_t r0 = sub * R;
+        const uint64_t r0 = sub * R;          // relative to this launch's first read
         const uint32_t nr = (uint32_t)((n_reads - r0) < (uint64_t)R ? (n_reads - r0) : (uint64_t)R);
         // the sub-tile's rows are nr * sw consecutive words (any stride 1..16: rows are not padded to 16 bytes,
         // they travel over PCIe); lane l takes words 4l .. 4l+3, the last lane of a ragged tail word by word
@@ -541,7 +540,7 @@ classify_kernel(DevIndex ix, QueryArgs a)
             const uint32_t gpr = (pmax + kPrePos - 1u) / kPrePos;  // position groups per read
             const uint32_t total = nr * gpr;
             const uint32_t mmask = m >= 16 ? 0xFFFFFFFFu : (1u << (2u * m)) - 1u;
-            for (uint32_t it = lane; it < total; it += 64) {
+            for (uint32_t it = lane; it < (CQ_EXP == 10 ? 0u : total); it += 64) {
                 const uint32_t rl = div_small(it, gpr, a.magic_pp), j = (it - __umul24(rl, gpr)) * kPrePos;
                 const uint32_t len = t.len[rl];
                 if (j + m > len) continue;
@@ -578,7 +577,7 @@ classify_kernel(DevIndex ix, QueryArgs a)
         const uint32_t total = nr * gpr;
         const uint32_t hmask = h < 16 ? (0xFFFFFFFFu >> (32u - 2u * h)) : 0xFFFFFFFFu;   // keys shorter than 32 bits
         uint32_t nw = 0;
-        for (uint32_t base = 0; base < total; base += 64) {
+        for (uint32_t base = 0; base < (CQ_EXP == 9 ? 0u : total); base += 64) {
             const uint32_t idx = base + lane;
             bool act = idx < total;
             uint32_t rl = 0, pw0 = 0, len = 0, fl = 0;
@@ -699,8 +698,9 @@ classify_kernel(DevIndex ix, QueryArgs a)
                     const bool f = ((kl.x ^ flo) < 2u) | (kl.y == flo) | (kl.z == flo) | (kl.w == flo) |
                                    ((kl.x ^ rlo) < 2u) | (kl.y == rlo) | (kl.z == rlo) | (kl.w == rlo) |
                                    ((kl.x & 1u) != 0) | (k >= bnd[NS]);   // run without a slot: no bucket was loaded, the exact path decides
-                    if (f && k < nwin) fl |= 1u << k;
+                    if (f && k < nwin && CQ_EXP != 8) fl |= 1u << k;
                 }
+                if (CQ_EXP == 8) fl = (mr[0] == 0x12345u) ? 1u : 0u;   // keep the minimizer work alive
             }
             // the one place where windows enter the work list (and where it is drained): a lane hands
             // over one flagged window per trip -- most passes see one trip or none
@@ -737,7 +737,7 @@ classify_kernel(DevIndex ix, QueryArgs a)
                 if (n > (uint32_t)CAP) {
                     if (!SLOW) {   // hand the read to the exact slow path
                         const uint32_t k = atomicAdd(a.ovf_count, 1u);
-                        if (k < a.ovf_cap) a.ovf_list[k] = (uint32_t)(r0 + lane);
+                        if (k < a.ovf_cap) a.ovf_list[k] = (uint32_t)(a.read0 + r0 + lane);   // index into the CALL's rows
                         atomicAdd(&t.scal[3], 1u);
                     }
                 } else if (CQ_EXP != 3) decide<CAP>(a, t, lane, n);
@@ -754,9 +754,10 @@ classify_kernel(DevIndex ix, QueryArgs a)
     // ---- flush workgroup-level counters
     __syncthreads();
     if (t.hist)
-        for (uint32_t i = tid; i < 2 * G1; i += kBlock) {
+        for (uint32_t i = tid; i < G1; i += kBlock) {
             const uint32_t v = t.hist[i];
-            if (v) atomicAdd((unsigned long long *)&a.counters[i], (unsigned long long)v);
+            if (v & 0xFFFFu) atomicAdd((unsigned long long *)&a.counters[i], (unsigned long long)(v & 0xFFFFu));
+            if (v >> 16) atomicAdd((unsigned long long *)&a.counters[G1 + i], (unsigned long long)(v >> 16));
         }
     if (tid < 4 && t.scal[tid]) {
         const uint64_t off[4] = {CQ_CTR_NUNDET(a.n_genomes), CQ_CTR_NCONF(a.n_genomes), CQ_CTR_NSKIP(a.n_genomes),
@@ -773,6 +774,7 @@ classify_kernel(DevIndex ix, QueryArgs a)
 #endif
 constexpr int kFastR = CQ_FAST_R, kFastCAP = CQ_FAST_CAP;
 constexpr int kSlowR = 1, kSlowCAP = 1024;
+constexpr uint64_t kMaxSubPerWave = 32767 / (kWaves * kFastR);   // 1023 sub-tiles: <= 32736 reads per workgroup and launch
 
 static size_t smem_bytes(int R, int CAP, const QueryArgs &a, bool hist)
 {
@@ -781,8 +783,8 @@ static size_t smem_bytes(int R, int CAP, const QueryArgs &a, bool hist)
 
 bool lds_hist_fits(uint32_t n_genomes)
 {
-    if (const char *v = getenv("CAMMIQ_LDS_HIST_MAX")) return 2 * ((size_t)n_genomes + 1) * 4 <= (size_t)atoi(v);   // tuning knob
-    return 2 * ((size_t)n_genomes + 1) * 4 <= 32 * 1024;
+    if (const char *v = getenv("CAMMIQ_LDS_HIST_MAX")) return ((size_t)n_genomes + 1) * 4 <= (size_t)atoi(v);   // tuning knob
+    return ((size_t)n_genomes + 1) * 4 <= 32 * 1024;
 }
 
 static uint32_t magic_of(uint32_t d) { return d == 0 ? 0u : (uint32_t)(((1u << 19) + d - 1) / d); }
@@ -824,10 +826,10 @@ hipError_t launch_classify(const DevIndex &ix, QueryArgs a, int n_cus, hipStream
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     // fast kernel: persistent waves, each walking its own sub-tiles
+    uint64_t grid_full = 1;
     {
         const size_t sm = smem_bytes(kFastR, kFastCAP, a, a.use_lds_hist);
         // persistent grid = what is resident (registers and LDS decide), at most 6 workgroups per CU
-        // (measured: 7-8 oversubscribe the L1 / TLB, -25 %)
         int per_cu = 0;
         e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)classify_kernel<kFastR, kFastCAP, false>,
                                                          kBlock, sm);
@@ -835,22 +837,43 @@ hipError_t launch_classify(const DevIndex &ix, QueryArgs a, int n_cus, hipStream
         if (per_cu > CQ_MAX_BLOCKS_PER_CU) per_cu = CQ_MAX_BLOCKS_PER_CU;
         if (const char *v = getenv("CAMMIQ_BLOCKS_PER_CU")) per_cu = atoi(v);   // tuning knob
         if (per_cu < 1) per_cu = 1;
-        const uint64_t n_sub = (a.n_reads + kFastR - 1) / kFastR;
-        uint64_t grid = (uint64_t)n_cus * per_cu;
-        const uint64_t need = (n_sub + kWaves - 1) / kWaves;
-        if (grid > need) grid = need;
-        if (grid == 0) grid = 1;
+        grid_full = (uint64_t)n_cus * per_cu;
+        // The LDS histogram keeps cnt_u and cnt_d of a genome in the two halves of one word; one read adds at most
+        // 1 to a genome's cnt_u and at most 2 to its cnt_d (a pair (g, g)), so a workgroup must not classify more than
+        // 32767 reads per launch: a wave takes at most kMaxSubPerWave sub-tiles, longer inputs are cut into several
+        // launches (configs[2]'s 50 M reads per launch still fit one: 1536 workgroups x 32736 reads).
+        uint64_t max_sub = kMaxSubPerWave;
+        if (const char *v = getenv("CAMMIQ_MAX_SUB_PER_WAVE")) max_sub = (uint64_t)atoi(v) >= 1 && (uint64_t)atoi(v) < max_sub ? (uint64_t)atoi(v) : max_sub;   // test knob
+        const uint64_t chunk = a.use_lds_hist ? grid_full * kWaves * max_sub * kFastR : a.n_reads;
+        const uint32_t *packed0 = a.packed;
+        const uint8_t *lens0 = a.lens;
+        const uint64_t n_total = a.n_reads;
         if (ev_start) { e = hipEventRecord(ev_start, stream); if (e != hipSuccess) return e; }
-        hipLaunchKernelGGL((classify_kernel<kFastR, kFastCAP, false>), dim3((unsigned)grid), dim3(kBlock), sm, stream, ix, a);
+        for (uint64_t c0 = 0; c0 < n_total; c0 += chunk) {
+            a.read0 = c0;
+            a.n_reads = n_total - c0 < chunk ? n_total - c0 : chunk;
+            a.packed = packed0 + c0 * a.stride_words;
+            a.lens = lens0 + c0;
+            const uint64_t n_sub = (a.n_reads + kFastR - 1) / kFastR;
+            uint64_t grid = grid_full;
+            const uint64_t need = (n_sub + kWaves - 1) / kWaves;
+            if (grid > need) grid = need;
+            if (grid == 0) grid = 1;
+            hipLaunchKernelGGL((classify_kernel<kFastR, kFastCAP, false>), dim3((unsigned)grid), dim3(kBlock), sm, stream, ix, a);
+            e = hipGetLastError();
+            if (e != hipSuccess) return e;
+        }
+        a.read0 = 0; a.n_reads = n_total; a.packed = packed0; a.lens = lens0;
         if (ev_mid) { e = hipEventRecord(ev_mid, stream); if (e != hipSuccess) return e; }
-        e = hipGetLastError();
-        if (e != hipSuccess) return e;
     }
-    // exact slow path for reads with more than kFastCAP hits (usually none: the kernel
-    // reads the count from device memory and exits at once)
+    // exact slow path for reads with more than kFastCAP hits (usually none: the kernel reads the count from
+    // device memory and exits at once).  One read per wave; enough workgroups that none takes more than 32767.
     {
         const size_t sm = smem_bytes(kSlowR, kSlowCAP, a, a.use_lds_hist);
-        hipLaunchKernelGGL((classify_kernel<kSlowR, kSlowCAP, true>), dim3((unsigned)(n_cus)), dim3(kBlock), sm, stream, ix, a);
+        uint64_t grid = (uint64_t)n_cus;
+        const uint64_t need = a.n_reads / 32000 + 1;
+        if (a.use_lds_hist && grid < need) grid = need;
+        hipLaunchKernelGGL((classify_kernel<kSlowR, kSlowCAP, true>), dim3((unsigned)grid), dim3(kBlock), sm, stream, ix, a);
         e = hipGetLastError();
         if (e != hipSuccess) return e;
         if (ev_stop) e = hipEventRecord(ev_stop, stream);

@@ -253,7 +253,7 @@ def test_benchmark_generator_world_matches_oracle(tmp_path, share):
 
 
 def test_many_genomes_use_global_counters(tmp_path):
-    """n_genomes above the LDS-histogram limit (4095) switches the per-genome counters to
+    """n_genomes above the LDS-histogram limit (8191) switches the per-genome counters to
     global atomics; results must not change."""
     gen = synth.clade_genomes(41, 3, 3, 2500, 0.03)
     u, d = synth.select_markers(gen, 22, 34, keep_every=2, seed=2)
@@ -313,3 +313,24 @@ def test_full_size_configs1_properties(tmp_path):
     ns = 100_000
     ref = oracle_lib.OracleIndex(pu, None).query(b[:ns * rl], o[:ns + 1], G, nthreads=16)
     assert_same(ix.query(b[:ns * rl], o[:ns + 1], G), ref, "slice vs oracle")
+
+
+def test_long_inputs_are_cut_into_several_launches(tmp_path, monkeypatch):
+    """The LDS histogram packs cnt_u | cnt_d of a genome into one word, so a workgroup takes at most 32767 reads
+    per launch and the launcher cuts longer inputs into several launches.  Force small launches (test knobs) and
+    check against the oracle: reads with few hits, reads that overflow into the exact slow path (their indices
+    must stay relative to the whole call), a pair leaf (g, g) that bumps cnt_d twice per read."""
+    gen = synth.clade_genomes(31, 1, 3, 1200, 0.05)
+    u, d = synth.select_markers(gen, 10, 16, keep_every=1, seed=0)        # dense: > 16 hits per read
+    d[b"ACGGTTCAAGGT"] = (2, 2, 1, 1)
+    pu, pd = build_index(tmp_path, u, d, 8)
+    dense = synth.simulate_reads(gen, 300, (60, 255), 0.005, 3)
+    sparse = [b"TTTTTTGTGTGTACGGTTCAAGGTAC", b"GTGTGTGTGTGTGTGTGTGTGTGT"] * 9000 + [b"A" * 30] * 2000
+    reads = sparse[:7000] + dense[:150] + sparse[7000:] + dense[150:]
+    b, o = synth.concat_reads(reads)
+    ref = oracle_lib.OracleIndex(pu, pd).query(b, o, len(gen), nthreads=8)
+    assert int(ref["cnt_d"][2]) >= 2 * 9000
+    monkeypatch.setenv("CAMMIQ_MAX_SUB_PER_WAVE", "1")
+    monkeypatch.setenv("CAMMIQ_BLOCKS_PER_CU", "1")                         # 256 x 4 waves x 1 sub-tile x 8 = 8192 reads per launch
+    got = cq.Index(pu, pd, device=0).query(b, o, len(gen))
+    assert_same(got, ref, "several launches")
