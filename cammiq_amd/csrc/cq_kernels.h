@@ -27,6 +27,7 @@ struct QueryArgs {
     uint32_t stride_words;
     uint32_t wmax;           // max windows per read in this batch: max_len - h + 1
     uint32_t pmax;           // max m-mer positions per read: max_len - m + 1   (set by the launcher)
+    uint32_t pstride;        // words per read in the LDS array of m-mer hashes (set by the launcher)
     uint32_t magic_w;        // ceil(2^19 / window groups per read), ceil(2^19 / pmax): exact small divisions
     uint32_t magic_p;
     uint32_t magic_s;        // ceil(2^19 / stride_words)

@@ -56,6 +56,9 @@ constexpr int kWaves = kBlock / 64;
 #ifndef CQ_WORK_DRAIN
 #define CQ_WORK_DRAIN 64
 #endif
+#ifndef CQ_HIT_PAD
+#define CQ_HIT_PAD 0   /* extra words per read in the hit lists: 1 makes the stride odd (the deciding lanes of a sub-tile on distinct banks) */
+#endif
 #ifndef CQ_NT_ROWS
 #define CQ_NT_ROWS 1   /* read rows are a read-once stream: nontemporal loads keep them from displacing buckets in L2 */
 #endif
@@ -135,18 +138,18 @@ __device__ __forceinline__ uint32_t row_base(const uint32_t *row, uint32_t q)
 // the per-genome histogram and four scalar counters are shared by the workgroup (atomics).
 struct SmemLayout { uint32_t rows, phi, len, hitcnt, hit_gid, hit_r1, hit_r2, nwork, work, per_wave, scal, hist, total; };
 
-__host__ __device__ inline SmemLayout smem_layout(int R, int CAP, uint32_t sw, uint32_t pmax, uint32_t n_genomes, bool hist)
+__host__ __device__ inline SmemLayout smem_layout(int R, int CAP, uint32_t sw, uint32_t pstride, uint32_t n_genomes, bool hist)
 {
     SmemLayout L;
     uint32_t o = 0;
     L.work = o;    o += 2u * kWorkCap;                 // uint2 list first: keeps it 8-byte aligned
-    L.rows = o;    o += (uint32_t)R * (sw + 2);
-    L.phi = o;     o += (uint32_t)R * pmax;
+    L.rows = o;    o += (uint32_t)R * (sw | 1u) + 3u;  // odd row stride (banks); +3: a ragged tail is stored as whole 16-byte pieces
+    L.phi = o;     o += (uint32_t)R * pstride;
     L.len = o;     o += (uint32_t)R;
     L.hitcnt = o;  o += (uint32_t)R;
-    L.hit_gid = o; o += (uint32_t)R * (uint32_t)CAP;
-    L.hit_r1 = o;  o += (uint32_t)R * (uint32_t)CAP;
-    L.hit_r2 = o;  o += (uint32_t)R * (uint32_t)CAP;
+    L.hit_gid = o; o += (uint32_t)R * (uint32_t)(CAP + CQ_HIT_PAD);
+    L.hit_r1 = o;  o += (uint32_t)R * (uint32_t)(CAP + CQ_HIT_PAD);
+    L.hit_r2 = o;  o += (uint32_t)R * (uint32_t)(CAP + CQ_HIT_PAD);
     L.nwork = o;   o += 1;
     o = (o + 3u) & ~3u;                                // 16-byte multiple per wave
     L.per_wave = o;
@@ -158,8 +161,8 @@ __host__ __device__ inline SmemLayout smem_layout(int R, int CAP, uint32_t sw, u
 }
 
 struct Tile {             // one wave's view of LDS
-    uint32_t *rows;      // [R][sw+2]  2-bit rows (+2 zero pad words)
-    uint32_t *phi;       // [R][pmax]  hash of the canonical m-mer starting at each base
+    uint32_t *rows;      // [R][sw|1]  2-bit rows; bases past a read's end are whatever follows (never used)
+    uint32_t *phi;       // [R][pstride]  hash of the canonical m-mer starting at each base (pstride: odd, >= pmax rounded up to 8)
     uint32_t *len;       // [R]        read length (0 = skip)
     uint32_t *hitcnt;    // [R]
     uint32_t *hit_gid;   // [R][CAP]
@@ -248,9 +251,9 @@ __device__ __forceinline__ void append_hit(const Tile &t, uint32_t rl, uint32_t 
     if (CQ_EXP == 7) { k = lane_id() & 7u; t.hitcnt[rl] = k + 1u; }   // diagnostic: no LDS atomic
     else k = atomicAdd(&t.hitcnt[rl], 1u);
     if (k < (uint32_t)CAP) {
-        t.hit_gid[rl * CAP + k] = gid;
-        t.hit_r1[rl * CAP + k] = r1;
-        t.hit_r2[rl * CAP + k] = r2;
+        t.hit_gid[rl * (CAP + CQ_HIT_PAD) + k] = gid;
+        t.hit_r1[rl * (CAP + CQ_HIT_PAD) + k] = r1;
+        t.hit_r2[rl * (CAP + CQ_HIT_PAD) + k] = r2;
     }
 }
 
@@ -289,14 +292,14 @@ __device__ __forceinline__ void resolve_pair(const DevIndex &ix, const Tile &t, 
 // chain, then trie walk + hit append for every table that holds the h-mer.  Runs only for
 // the few windows the probe loop flagged, one window per lane, all lanes busy.
 template <int CAP>
-__device__ __forceinline__ void lookup_window(const DevIndex &ix, const Tile &t, uint32_t swp, uint32_t pmax, uint32_t rl,
+__device__ __forceinline__ void lookup_window(const DevIndex &ix, const Tile &t, uint32_t swp, uint32_t pstride, uint32_t rl,
                                               uint32_t pw, uint32_t b)
 {
     const uint32_t h = ix.hash_len;
     const uint32_t *row = t.rows + rl * swp;
     const uint32_t len = t.len[rl];
     if (b == kNoBucket) {   // the probe loop kept no bucket for this window (fourth minimizer of its lane): look it up again
-        const uint32_t *ph = t.phi + rl * pmax + pw;
+        const uint32_t *ph = t.phi + rl * pstride + pw;
         uint32_t v = ph[0];
         for (uint32_t i = 1; i + ix.minimizer_len <= h; i++) v = min(v, ph[i]);
         b = cq_bucket_of_minimizer(v, ix.n_buckets);
@@ -320,12 +323,12 @@ __device__ __forceinline__ void lookup_window(const DevIndex &ix, const Tile &t,
 
 // Drain this wave's work list (n <= kWorkCap items: .x = bucket, .y = read | window << 8).
 template <int CAP>
-__device__ __forceinline__ void drain_work(const DevIndex &ix, const Tile &t, uint32_t swp, uint32_t pmax, uint32_t n)
+__device__ __forceinline__ void drain_work(const DevIndex &ix, const Tile &t, uint32_t swp, uint32_t pstride, uint32_t n)
 {
     wave_sync();
     for (uint32_t i = lane_id(); i < n; i += 64) {
         const uint2 it = t.work[i];
-        lookup_window<CAP>(ix, t, swp, pmax, it.y & 255u, it.y >> 8, it.x);
+        lookup_window<CAP>(ix, t, swp, pstride, it.y & 255u, it.y >> 8, it.x);
     }
     wave_sync();
 }
@@ -361,7 +364,7 @@ __device__ __forceinline__ void pair_add(const QueryArgs &a, uint32_t pa, uint32
 template <int CAP>
 __device__ __forceinline__ void decide(const QueryArgs &a, const Tile &t, uint32_t rl, uint32_t n)
 {
-    const uint32_t *gid = t.hit_gid + rl * CAP, *r1 = t.hit_r1 + rl * CAP, *r2 = t.hit_r2 + rl * CAP;
+    const uint32_t *gid = t.hit_gid + rl * (CAP + CQ_HIT_PAD), *r1 = t.hit_r1 + rl * (CAP + CQ_HIT_PAD), *r2 = t.hit_r2 + rl * (CAP + CQ_HIT_PAD);
     uint32_t nU = 0, u0 = 0, nP = 0, pa = 0, pb = 0, ia = 0, ib = 0;
     bool va = false, vb = false;
     uint32_t dupmask = 0;                   // CAP <= 32: bit i = hit i repeats an earlier leaf
@@ -433,12 +436,12 @@ classify_kernel(DevIndex ix, QueryArgs a)
 {
     static_assert(SLOW || R * 4 <= 64, "a sub-tile's rows (R x <= 16 words) must fit one 16-byte load per lane");
     extern __shared__ __align__(16) uint32_t smem[];
-    const uint32_t sw = a.stride_words, swp = sw + 2;
+    const uint32_t sw = a.stride_words, swp = sw | 1u;
     const uint32_t G1 = a.n_genomes + 1;
     const uint32_t h = ix.hash_len, m = ix.minimizer_len, nphi = h - m + 1;
-    const uint32_t wmax = a.wmax, pmax = a.pmax;
+    const uint32_t wmax = a.wmax, pmax = a.pmax, pstride = a.pstride;
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
-    const SmemLayout L = smem_layout(R, CAP, sw, pmax, a.n_genomes, a.use_lds_hist != 0);
+    const SmemLayout L = smem_layout(R, CAP, sw, pstride, a.n_genomes, a.use_lds_hist != 0);
     uint32_t *mine = smem + wave * L.per_wave;
     Tile t;
     t.work = (uint2 *)(mine + L.work);
@@ -502,18 +505,16 @@ classify_kernel(DevIndex ix, QueryArgs a)
         if (!SLOW) {
             const uint32_t nwords = nr * sw, w = lane * 4;
             if (w < nwords) {
-                if ((sw & 3u) == 0) {   // a 16-byte piece lies inside one row
-                    const uint32_t rl = div_small(w, sw, a.magic_s), c = w - __umul24(rl, sw);
-                    uint32_t *dst = t.rows + rl * swp + c;
+                if (swp == sw) {        // odd stride: the sub-tile's image in LDS is its image in HBM, one 16-byte store per lane
+                    uint32_t *dst = t.rows + w;
                     dst[0] = pf_row.x; dst[1] = pf_row.y; dst[2] = pf_row.z; dst[3] = pf_row.w;
-                } else {                // word by word: row r starts at word r * sw of the piece stream
+                } else {                // even stride: rows are spread to stride sw + 1, word by word
                     const uint32_t v[4] = {pf_row.x, pf_row.y, pf_row.z, pf_row.w};
+                    uint32_t wv = w;
+                    asm volatile("" : "+v"(wv));   // not loop-invariant for the compiler: four hoisted addresses would cost registers on the odd-stride path
 #pragma unroll
                     for (uint32_t i = 0; i < 4; i++)
-                        if (w + i < nwords) {
-                            const uint32_t rl = div_small(w + i, sw, a.magic_s), c = w + i - __umul24(rl, sw);
-                            t.rows[rl * swp + c] = v[i];
-                        }
+                        if (wv + i < nwords) t.rows[wv + i + div_small(wv + i, sw, a.magic_s)] = v[i];
                 }
             }
         } else {
@@ -527,7 +528,6 @@ classify_kernel(DevIndex ix, QueryArgs a)
             if (lane < nr) len = SLOW ? a.lens[a.ovf_list[r0 + lane]] : pf_len;
             t.len[lane] = len;
             t.hitcnt[lane] = 0;
-            t.rows[lane * swp + sw] = 0; t.rows[lane * swp + sw + 1] = 0;   // pad words read by the window extract
         }
         if (!SLOW) prefetch(sub + n_waves);   // in flight while this sub-tile is processed
         wave_sync();
@@ -547,13 +547,15 @@ classify_kernel(DevIndex ix, QueryArgs a)
                 const uint32_t *row = t.rows + __umul24(rl, swp);
                 const uint64_t w64 = row_bits64(row, (int)j);      // 32 bases starting at base j
                 const uint64_t rc64 = ~rev2(w64);
-                const uint32_t nv = len - m - j;                   // positions j .. j + min(nv, kPrePos-1) are valid
-                uint32_t *dst = t.phi + __umul24(rl, pmax) + j;
+                uint32_t *dst = t.phi + __umul24(rl, pstride) + j;
+                // all kPrePos positions of the group are hashed and stored, valid or not (a row of phi holds whole
+                // groups): positions past len - m get the hash of whatever follows the read and are never read by a
+                // valid window -- no per-position branch
 #pragma unroll
                 for (uint32_t k = 0; k < kPrePos; k++) {
                     const uint32_t f = (uint32_t)((w64 << (2u * k)) >> (64u - 2u * m));
                     const uint32_t r = (uint32_t)(rc64 >> (2u * k)) & mmask;
-                    if (k <= nv) dst[k] = cq_phi32(f < r ? f : r);
+                    dst[k] = cq_phi32(f < r ? f : r);
                 }
             }
         }
@@ -597,7 +599,7 @@ classify_kernel(DevIndex ix, QueryArgs a)
             if (act) {
                 const uint32_t nwin = len - h + 1u - pw0;         // valid windows from pw0 on (>= 1)
                 // minimizer hash of every window = min over its h-m+1 m-mers
-                const uint32_t *ph = t.phi + __umul24(rl, pmax) + pw0;
+                const uint32_t *ph = t.phi + __umul24(rl, pstride) + pw0;
                 uint32_t mp[KW];
                 if (nphi == 11 && KW == 4) {   // h = 26 (CAMMiQ's default): fourteen LDS reads serve four windows
                     const uint32_t v0 = ph[0], v1 = ph[1], v2 = ph[2], v3 = ph[3], v4 = ph[4], v5 = ph[5], v6 = ph[6],
@@ -720,11 +722,11 @@ classify_kernel(DevIndex ix, QueryArgs a)
                     t.work[off] = make_uint2(b, rl | ((pw0 + k) << 8));
                 }
                 nw += (uint32_t)__popcll(mask);
-                if (nw >= (uint32_t)kWorkDrain) { CQ_STAMP(2); if (CQ_EXP != 1) drain_work<CAP>(ix, t, swp, pmax, nw); nw = 0; CQ_STAMP(3); }
+                if (nw >= (uint32_t)kWorkDrain) { CQ_STAMP(2); if (CQ_EXP != 1) drain_work<CAP>(ix, t, swp, pstride, nw); nw = 0; CQ_STAMP(3); }
             }
         }
         CQ_STAMP(2);   // probe loop
-        if (nw && CQ_EXP != 1) drain_work<CAP>(ix, t, swp, pmax, nw);
+        if (nw && CQ_EXP != 1) drain_work<CAP>(ix, t, swp, pstride, nw);
         CQ_STAMP(3);   // exact lookups
         wave_sync();
 
@@ -778,7 +780,7 @@ constexpr uint64_t kMaxSubPerWave = 32767 / (kWaves * kFastR);   // 1023 sub-til
 
 static size_t smem_bytes(int R, int CAP, const QueryArgs &a, bool hist)
 {
-    return (size_t)smem_layout(R, CAP, a.stride_words, a.pmax, a.n_genomes, hist).total * 4;
+    return (size_t)smem_layout(R, CAP, a.stride_words, a.pstride, a.n_genomes, hist).total * 4;
 }
 
 bool lds_hist_fits(uint32_t n_genomes)
@@ -813,6 +815,7 @@ hipError_t launch_classify(const DevIndex &ix, QueryArgs a, int n_cus, hipStream
 {
     a.use_lds_hist = lds_hist_fits(a.n_genomes) ? 1 : 0;
     a.pmax = a.wmax + (ix.hash_len - ix.minimizer_len);   // m-mer positions: max_len - m + 1
+    a.pstride = ((a.pmax + kPrePos - 1u) / kPrePos * kPrePos) | 1u;   // whole position groups (the pre-pass stores unconditionally), odd (banks)
     a.magic_w = magic_of((a.wmax + kWinPerLane - 1u) / kWinPerLane);
     a.magic_p = magic_of(a.pmax);
     a.magic_s = magic_of(a.stride_words);

@@ -1,0 +1,117 @@
+// valu_bench.hip -- issue cost of the integer VALU / SALU instructions the classify kernel is made of, per SIMD,
+// with 1..8 waves resident per SIMD (MI355X_MICROARCH.md quotes 2 cycles per wave64 v_fma_f32 with several waves
+// resident; DESIGN.md section 6 needs the figure for v_add/v_cmp/v_cndmask/v_mul_lo/64-bit shifts).
+//   hipcc --offload-arch=gfx950 -O3 tools/valu_bench.hip -o tools/valu_bench
+// Every block is 256 threads = one wave per SIMD of a CU; W blocks per CU = W waves per SIMD.  Each wave runs ITER
+// times through an unrolled asm body of 64 instructions on 8 independent registers.  cycles/instr = elapsed
+// s_memtime cycles (100 MHz constant clock is NOT used: wall time x the shader clock reported by the runtime) x
+// ... / (ITER x 64 x W), i.e. the SIMD's issue interval per wave-instruction.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstdint>
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
+
+#define REP8(s0, s1, s2, s3, s4, s5, s6, s7) s0 s1 s2 s3 s4 s5 s6 s7
+#define BODY64(I) REP8(I(0), I(1), I(2), I(3), I(4), I(5), I(6), I(7)) REP8(I(0), I(1), I(2), I(3), I(4), I(5), I(6), I(7)) \
+                  REP8(I(0), I(1), I(2), I(3), I(4), I(5), I(6), I(7)) REP8(I(0), I(1), I(2), I(3), I(4), I(5), I(6), I(7)) \
+                  REP8(I(0), I(1), I(2), I(3), I(4), I(5), I(6), I(7)) REP8(I(0), I(1), I(2), I(3), I(4), I(5), I(6), I(7)) \
+                  REP8(I(0), I(1), I(2), I(3), I(4), I(5), I(6), I(7)) REP8(I(0), I(1), I(2), I(3), I(4), I(5), I(6), I(7))
+
+#define I_ADD(k) "v_add_u32 %" #k ", %" #k ", %8\n"
+#define I_XOR(k) "v_xor_b32 %" #k ", %" #k ", %8\n"
+#define I_MIN(k) "v_min_u32 %" #k ", %" #k ", %8\n"
+#define I_MUL(k) "v_mul_lo_u32 %" #k ", %" #k ", %8\n"
+#define I_MUL24(k) "v_mul_u32_u24 %" #k ", %" #k ", %8\n"
+#define I_ALIGN(k) "v_alignbit_b32 %" #k ", %" #k ", %8, 7\n"
+#define I_CNDM(k) "v_cndmask_b32 %" #k ", %" #k ", %8, vcc\n"
+#define I_CMP(k) "v_cmp_eq_u32 vcc, %" #k ", %8\n"
+#define I_CMPS(k) "v_cmp_eq_u32 s[20:21], %" #k ", %8\ns_or_b64 s[22:23], s[22:23], s[20:21]\n"
+#define I_SOR(k) "s_or_b64 s[22:23], s[22:23], s[20:21]\n"
+#define I_BFREV(k) "v_bfrev_b32 %" #k ", %" #k "\n"
+
+#define KERNEL(name, INSTR, CLOB)                                                                         \
+    __global__ void __launch_bounds__(256) name(uint32_t *out, int iters, uint32_t kk)                    \
+    {                                                                                                     \
+        uint32_t a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7; \
+        uint32_t k = kk | 1u;                                                                             \
+        for (int i = 0; i < iters; i++)                                                                   \
+            asm volatile(BODY64(INSTR) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(k) : CLOB); \
+        if ((a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7) == 0x12345678u) out[0] = a0;                          \
+    }
+
+KERNEL(k_add, I_ADD, "vcc")
+KERNEL(k_xor, I_XOR, "vcc")
+KERNEL(k_min, I_MIN, "vcc")
+KERNEL(k_mul, I_MUL, "vcc")
+KERNEL(k_mul24, I_MUL24, "vcc")
+KERNEL(k_align, I_ALIGN, "vcc")
+KERNEL(k_cndmask, I_CNDM, "vcc")
+KERNEL(k_cmp, I_CMP, "vcc")
+KERNEL(k_bfrev, I_BFREV, "vcc")
+#define CLOB_S "vcc", "s20", "s21", "s22", "s23"
+KERNEL(k_cmp_sor, I_CMPS, CLOB_S)
+KERNEL(k_sor, I_SOR, CLOB_S)
+
+// 64-bit shift: operates on register pairs
+__global__ void __launch_bounds__(256) k_shr64(uint32_t *out, int iters, uint32_t kk)
+{
+    uint64_t a0 = threadIdx.x * 0x9E3779B97F4A7C15ull, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3;
+    uint32_t k = (kk & 7u) | 1u;
+    for (int i = 0; i < iters; i++)
+        asm volatile(
+#define S64(k) "v_lshrrev_b64 %" #k ", %4, %" #k "\n"
+            REP8(S64(0), S64(1), S64(2), S64(3), S64(0), S64(1), S64(2), S64(3)) REP8(S64(0), S64(1), S64(2), S64(3), S64(0), S64(1), S64(2), S64(3))
+            REP8(S64(0), S64(1), S64(2), S64(3), S64(0), S64(1), S64(2), S64(3)) REP8(S64(0), S64(1), S64(2), S64(3), S64(0), S64(1), S64(2), S64(3))
+            REP8(S64(0), S64(1), S64(2), S64(3), S64(0), S64(1), S64(2), S64(3)) REP8(S64(0), S64(1), S64(2), S64(3), S64(0), S64(1), S64(2), S64(3))
+            REP8(S64(0), S64(1), S64(2), S64(3), S64(0), S64(1), S64(2), S64(3)) REP8(S64(0), S64(1), S64(2), S64(3), S64(0), S64(1), S64(2), S64(3))
+            : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(k));
+    if ((a0 ^ a1 ^ a2 ^ a3) == 0x12345678u) out[0] = (uint32_t)a0;
+}
+
+template <typename K>
+void run(const char *name, K kern, uint32_t *out, int n_cus, double mhz, int per_instr)
+{
+    const int iters = 20000;
+    for (int w : {1, 2, 4, 6, 8}) {
+        hipEvent_t a, b;
+        CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+        kern<<<n_cus * w, 256>>>(out, 100, 3);
+        CK(hipDeviceSynchronize());
+        CK(hipEventRecord(a));
+        kern<<<n_cus * w, 256>>>(out, iters, 3);
+        CK(hipEventRecord(b));
+        CK(hipEventSynchronize(b));
+        float ms;
+        CK(hipEventElapsedTime(&ms, a, b));
+        const double cyc = ms * 1e-3 * mhz * 1e6;                       // shader cycles of the launch
+        const double instr_per_simd = (double)iters * 64 * per_instr * w;   // wave-instructions one SIMD issued
+        printf("%-12s %d waves/SIMD: %7.3f ms  -> %.2f cycles per wave-instruction per SIMD (at %.0f MHz)\n", name, w, ms,
+               cyc / instr_per_simd, mhz);
+    }
+}
+
+int main()
+{
+    hipDeviceProp_t p;
+    CK(hipGetDeviceProperties(&p, 0));
+    const double mhz = p.clockRate / 1000.0;
+    printf("%s: %d CUs, clockRate %.0f MHz\n", p.name, p.multiProcessorCount, mhz);
+    uint32_t *out;
+    CK(hipMalloc(&out, 4));
+    const int n = p.multiProcessorCount;
+    run("v_add_u32", k_add, out, n, mhz, 1);
+    run("v_xor_b32", k_xor, out, n, mhz, 1);
+    run("v_min_u32", k_min, out, n, mhz, 1);
+    run("v_alignbit", k_align, out, n, mhz, 1);
+    run("v_cndmask", k_cndmask, out, n, mhz, 1);
+    run("v_cmp->vcc", k_cmp, out, n, mhz, 1);
+    run("v_bfrev", k_bfrev, out, n, mhz, 1);
+    run("v_mul_u24", k_mul24, out, n, mhz, 1);
+    run("v_mul_lo_u32", k_mul, out, n, mhz, 1);
+    run("v_lshrrev_b64", k_shr64, out, n, mhz, 1);
+    run("s_or_b64", k_sor, out, n, mhz, 1);
+    run("v_cmp+s_or", k_cmp_sor, out, n, mhz, 2);
+    return 0;
+}
