@@ -306,7 +306,9 @@ def main():
                     roof["physical_GBs"] = round(hb / (k_ms * 1e-3) / 1e9, 2)
                     roof["physical_frac"] = round(hb / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
                     if ent.get("gather_ceiling_lines_per_s"):
-                        lines = hb / 64.0 / (k_ms * 1e-3)
+                        # 64-byte lines READ per second (FETCH_SIZE; writes left out) against the chip's measured rate of
+                        # random 16-byte loads from a table of this size
+                        lines = float(ent.get("fetch_bytes_per_launch", hb)) / 64.0 / (k_ms * 1e-3)
                         roof["gather_ceiling_frac"] = round(lines / float(ent["gather_ceiling_lines_per_s"]), 5)
                         roof["gather_ceiling_note"] = ent.get("gather_ceiling_note")
             result = {

@@ -57,6 +57,7 @@ SIGNATURES = {
     "cq_pack_stride_words": (C.c_uint32, [C.c_uint32]),
     "cq_pack_reads": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p,
                                 C.c_void_p, C.POINTER(C.c_uint64)]),
+    "cq_pack_read": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
     "cq_counter_words": (C.c_uint64, [C.c_uint32]),
     "cq_query_device": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32,
                                   C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),

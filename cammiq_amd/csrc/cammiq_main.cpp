@@ -100,17 +100,22 @@ std::vector<Genome> load_map(const std::string &fn)
 // Unlike the reference (one getline + one new[] per read, single thread) the file is
 // memory-mapped and split at line boundaries across threads.  Two passes: (1) every chunk counts
 // its lines and, for each of the four possible positions of its first line in a FASTQ record, the
-// sequence lines and their bytes it would contribute; a prefix sum over the chunks then fixes
-// everything; (2) every chunk copies its sequence lines into one contiguous buffer + offsets,
-// which is what cq_query takes.  The output buffers are not initialised first (their pages are
+// sequence lines, their bytes and their longest length; a prefix sum over the chunks then fixes
+// everything; (2) every chunk packs its sequence lines straight into 2-bit rows (cq_pack_read),
+// which is what cq_query_packed takes -- the ASCII reads are never copied (--fastq_stats keeps an
+// ASCII pass 2 for its digest).  The output buffers are not initialised first (their pages are
 // first touched by the copying threads).
 struct Reads {
-    std::unique_ptr<uint8_t[]> bases;
+    std::unique_ptr<uint8_t[]> bases;   // ASCII (--fastq_stats only)
     std::unique_ptr<uint64_t[]> offs;   // n_reads + 1
+    std::unique_ptr<uint32_t[]> packed; // 2-bit rows, stride sw words (queries: the ASCII reads are never materialised)
+    std::unique_ptr<uint8_t[]> lens;
+    uint32_t sw = 1, max_len = 0;
     size_t n_reads = 0, n_bases = 0;
 };
 
-void read_fastq(const std::string &fn, size_t min_l, Reads &out)
+// pack = true: pass 2 writes 2-bit rows (cq_pack_read) straight from the mapped file instead of an ASCII copy.
+void read_fastq(const std::string &fn, size_t min_l, Reads &out, bool pack = false)
 {
     const bool timing = getenv("CAMMIQ_LOAD_TIMING") != nullptr;
     const auto t_begin = std::chrono::steady_clock::now();
@@ -142,7 +147,7 @@ void read_fastq(const std::string &fn, size_t min_l, Reads &out)
         for (auto &x : th) x.join();
     };
     // pass 1: lines per chunk; kept reads / bytes for each residue (line number within the chunk) mod 4
-    struct Count { uint64_t lines = 0, reads[4] = {0, 0, 0, 0}, bytes[4] = {0, 0, 0, 0}; };
+    struct Count { uint64_t lines = 0, reads[4] = {0, 0, 0, 0}, bytes[4] = {0, 0, 0, 0}; uint32_t maxlen[4] = {0, 0, 0, 0}; };
     std::vector<Count> cnt(T);
     for_chunks([&](unsigned c) {
         Count k;
@@ -150,7 +155,10 @@ void read_fastq(const std::string &fn, size_t min_l, Reads &out)
             const char *nl = (const char *)memchr(s, '\n', (size_t)(e - s));
             size_t len = nl ? (size_t)(nl - s) : (size_t)(e - s);
             if (len && s[len - 1] == '\r') len--;
-            if (len >= min_l) { k.reads[k.lines & 3u]++; k.bytes[k.lines & 3u] += len; }
+            if (len >= min_l) {
+                k.reads[k.lines & 3u]++; k.bytes[k.lines & 3u] += len;
+                if (len <= 255 && len > k.maxlen[k.lines & 3u]) k.maxlen[k.lines & 3u] = (uint32_t)len;
+            }
             k.lines++;
             if (!nl) break;
             s = nl + 1;
@@ -164,32 +172,54 @@ void read_fastq(const std::string &fn, size_t min_l, Reads &out)
         line0[c + 1] = line0[c] + cnt[c].lines;
         r0[c + 1] = r0[c] + cnt[c].reads[res];
         b0[c + 1] = b0[c] + cnt[c].bytes[res];
+        out.max_len = std::max(out.max_len, cnt[c].maxlen[res]);
     }
     out.n_reads = r0[T];
     out.n_bases = b0[T];
-    out.bases.reset(new uint8_t[out.n_bases ? out.n_bases : 1]);
-    out.offs.reset(new uint64_t[out.n_reads + 1]);
-    out.offs[out.n_reads] = out.n_bases;
+    out.sw = cq_pack_stride_words(out.max_len);
+    const uint32_t sw = out.sw;
+    if (pack) {
+        out.packed.reset(new uint32_t[out.n_reads * sw + 1]);
+        out.lens.reset(new uint8_t[out.n_reads + 1]);
+    } else {
+        out.bases.reset(new uint8_t[out.n_bases ? out.n_bases : 1]);
+        out.offs.reset(new uint64_t[out.n_reads + 1]);
+        out.offs[out.n_reads] = out.n_bases;
+    }
     // pass 2: copy
     const char alphabet[4] = {'A', 'C', 'G', 'T'};
     uint8_t *const bases = out.bases.get();
     uint64_t *const offs = out.offs.get();
+    uint32_t *const packed = out.packed.get();
+    uint8_t *const lens = out.lens.get();
     for_chunks([&](unsigned c) {
         uint64_t r = r0[c], b = b0[c], li = line0[c];
+        uint8_t tmp[256];
         for (const char *s = p + cut[c], *e = p + cut[c + 1]; s < e; li++) {
             const char *nl = (const char *)memchr(s, '\n', (size_t)(e - s));
             size_t len = nl ? (size_t)(nl - s) : (size_t)(e - s);
             if ((li & 3u) == 1u) {
                 if (len && s[len - 1] == '\r') len--;
                 if (len >= min_l) {
-                    offs[r++] = b;
-                    uint8_t *dst = bases + b;
-                    memcpy(dst, s, len);
-                    if (memchr(dst, 'N', len)) {
-                        uint64_t z = ((li >> 2) + 1) * 0x9E3779B97F4A7C15ull;
-                        z ^= z >> 29;
-                        const uint8_t sub = (uint8_t)alphabet[(z >> 7) & 3];
-                        for (size_t i = 0; i < len; i++) if (dst[i] == 'N') dst[i] = sub;
+                    const bool has_n = memchr(s, 'N', len) != nullptr;
+                    uint64_t z = ((li >> 2) + 1) * 0x9E3779B97F4A7C15ull;
+                    z ^= z >> 29;
+                    const uint8_t sub = (uint8_t)alphabet[(z >> 7) & 3];
+                    if (pack) {
+                        const uint8_t *src = (const uint8_t *)s;
+                        if (has_n && len <= 255) {
+                            for (size_t i = 0; i < len; i++) tmp[i] = s[i] == 'N' ? sub : (uint8_t)s[i];
+                            src = tmp;
+                        }
+                        // reads longer than 255 bases are outside the parity domain (the reference keeps lengths in a uint8_t)
+                        if (len > 255) { memset(packed + r * sw, 0, (size_t)sw * 4); lens[r] = 0; }
+                        else cq_pack_read(src, (uint32_t)len, 1, sw, packed + r * sw, lens + r);
+                        r++;
+                    } else {
+                        offs[r++] = b;
+                        uint8_t *dst = bases + b;
+                        memcpy(dst, s, len);
+                        if (has_n) for (size_t i = 0; i < len; i++) if (dst[i] == 'N') dst[i] = sub;
                     }
                     b += len;
                 }
@@ -346,7 +376,7 @@ int main(int argc, char **argv)
     auto parse_async = [&](size_t f) {
         return std::async(std::launch::async, [&, f] {
             Reads p;
-            read_fastq(fq_names[f], min_rl, p);
+            read_fastq(fq_names[f], min_rl, p, true);   // straight to 2-bit rows
             return p;
         });
     };
@@ -417,8 +447,8 @@ int main(int argc, char **argv)
             c.cnt_u = cu.data(); c.cnt_d = cd.data();
             c.rcount_u = ru.empty() ? nullptr : ru.data(); c.rcount_d = rd.empty() ? nullptr : rd.data();
             c.pair_a = pa.data(); c.pair_b = pb.data(); c.pair_cnt = pc.data(); c.pair_cap = pc.size();
-            rc = mx ? cq_multi_query(mx, qmode, fq.bases.get(), fq.offs.get(), fq.n_reads, G, &c)
-                    : cq_query(ix, qmode, fq.bases.get(), fq.offs.get(), fq.n_reads, G, &c);
+            rc = mx ? cq_multi_query_packed(mx, qmode, fq.packed.get(), fq.lens.get(), fq.n_reads, fq.sw, fq.max_len, G, &c)
+                    : cq_query_packed(ix, qmode, fq.packed.get(), fq.lens.get(), fq.n_reads, fq.sw, fq.max_len, G, &c);
             if (rc == CQ_ERR_LIMIT && c.n_pairs > pc.size()) {   // read_cnts_b has more entries than the arrays: grow, ask again
                 pa.resize(c.n_pairs); pb.resize(c.n_pairs); pc.resize(c.n_pairs);
                 if (!mx) {   // the single-GPU library kept the pairs: fetch them, no second classify

@@ -119,6 +119,16 @@ extern "C" uint32_t cq_pack_stride_words(uint32_t max_len)
     return w ? w : 1;
 }
 
+extern "C" int cq_pack_read(const uint8_t *seq, uint32_t len, uint32_t hash_len, uint32_t stride_words, uint32_t *row,
+                            uint8_t *len_out)
+{
+    if (!row || !len_out || stride_words == 0 || stride_words > 16 || (!seq && len)) return CQ_ERR_ARG;
+    const uint64_t off[2] = {0, len};
+    uint64_t sk = 0;
+    pack_range(seq, off, 0, 1, hash_len, stride_words, row, len_out, &sk);
+    return CQ_OK;
+}
+
 extern "C" int cq_pack_reads(const uint8_t *bases, const uint64_t *offsets, uint64_t n_reads,
                              uint32_t hash_len, uint32_t stride_words, uint32_t *packed, uint8_t *lens,
                              uint64_t *n_skipped)

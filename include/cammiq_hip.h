@@ -179,6 +179,13 @@ int cq_pack_reads(const uint8_t *bases, const uint64_t *offsets, uint64_t n_read
                   uint32_t hash_len, uint32_t stride_words, uint32_t *packed, uint8_t *lens,
                   uint64_t *n_skipped);
 
+/* One read (seq[0..len)) into one row of stride_words words; *len_out = len, or 0 when the read is outside the
+ * parity domain.  Thread-safe, allocation-free: a FASTQ parser's threads call it on the sequence lines of a
+ * memory-mapped file and never materialise the ASCII reads (cammiq_main.cpp).  hash_len = 1 leaves the
+ * "shorter than h" rule to the kernel, which counts such reads in nskipped as well. */
+int cq_pack_read(const uint8_t *seq, uint32_t len, uint32_t hash_len, uint32_t stride_words, uint32_t *row,
+                 uint8_t *len_out);
+
 /* Number of uint64 in the device counter block for n_genomes:
  * [cnt_u[G+1] | cnt_d[G+1] | nundet nconf nskipped flags nslow 0 0 0].  flags != 0: increments of the
  * SC pair map were lost (map full).  Every word adds up across GPUs, flags included. */

@@ -204,3 +204,44 @@ def test_cli_several_fastq_files(tmp_path):
         total = [a + c for a, c in zip(total, want)]
     assert total == [412, 317, 404, 417]          # the whole sample
     assert r.stderr.count("Time for query:") == 3 and r.stderr.count("Loaded query file") == 3
+
+
+@pytest.mark.gpu
+def test_cli_packs_fastq_straight_to_two_bit_rows(tmp_path):
+    """Queries never materialise the ASCII reads: pass 2 of the FASTQ loader packs every sequence line with
+    cq_pack_read.  Reads with N (one substitute base per read, derived from the record number), lower case, CR LF,
+    reads shorter than h and longer than 255 bases: the TSV must equal cq_query on the substituted reads."""
+    import numpy as np
+    import cammiq_amd as cq
+    g = golden("survey_F1")
+    M = (1 << 64) - 1
+    rng = np.random.default_rng(5)
+    reads = []
+    for i, r in enumerate(g["reads"][:1500]):
+        r = bytearray(r)
+        if i % 7 == 0:
+            for j in rng.choice(len(r), 2, replace=False):
+                r[j] = ord("N")
+        if i % 11 == 0:
+            r = bytearray(bytes(r).lower().replace(b"n", b"N"))
+        reads.append(bytes(r))
+    reads += [b"ACGT", g["reads"][3] * 4, b"ACGTNACGT" * 3]                      # too short, too long (> 255), short with N
+    fq = tmp_path / "n.fastq"
+    fq.write_bytes(b"".join(b"@r%d\r\n%s\r\n+\r\n%s\r\n" % (i, r, b"I" * len(r)) for i, r in enumerate(reads)))
+    out = tmp_path / "out.txt"
+    r = _run(["--query", "--read_cnts", "-f", os.path.join(g["dir"], "genome_map.out"), "-i", g["pu"], g["pd"],
+              "-q", str(fq), "-o", str(out)])
+    assert r.returncode == 0, r.stderr
+    sub = []
+    for rec, s in enumerate(reads):
+        if b"N" in s:
+            z = ((rec + 1) * 0x9E3779B97F4A7C15) & M
+            z ^= z >> 29
+            s = s.replace(b"N", b"ACGT"[(z >> 7) & 3:((z >> 7) & 3) + 1])
+        sub.append(s)
+    b, o = synth.concat_reads(sub)
+    want = cq.Index(g["pu"], g["pd"], device=0).query(b, o, g["G"], mode=cq.MODE_SC)
+    got = [int(x) for x in out.read_text().splitlines()[1].split("\t")[1:]]
+    assert got == [int(x) for x in want["cnt_u"][1:]]
+    assert f"Number of unlabeled reads: {want['nundet']}." in r.stderr
+    assert want["nskipped"] == 2 and "(skipped): 2." in r.stderr
