@@ -813,13 +813,22 @@ hipError_t launch_accumulate(uint64_t *dst64, const uint64_t *src64, uint64_t n6
 hipError_t launch_classify(const DevIndex &ix, QueryArgs a, int n_cus, hipStream_t stream,
                            hipEvent_t ev_start, hipEvent_t ev_mid, hipEvent_t ev_stop)
 {
-    a.use_lds_hist = lds_hist_fits(a.n_genomes) ? 1 : 0;
     a.pmax = a.wmax + (ix.hash_len - ix.minimizer_len);   // m-mer positions: max_len - m + 1
     a.pstride = ((a.pmax + kPrePos - 1u) / kPrePos * kPrePos) | 1u;   // whole position groups (the pre-pass stores unconditionally), odd (banks)
     a.magic_w = magic_of((a.wmax + kWinPerLane - 1u) / kWinPerLane);
     a.magic_p = magic_of(a.pmax);
     a.magic_s = magic_of(a.stride_words);
     a.magic_pp = magic_of((a.pmax + kPrePos - 1u) / kPrePos);
+    // Per-genome counters: an LDS histogram per workgroup when it costs no resident workgroup (six per CU is what
+    // the registers allow), global 64-bit atomics otherwise -- measured: the atomics cost 4 %, a lost workgroup 8 %.
+    a.use_lds_hist = lds_hist_fits(a.n_genomes) ? 1 : 0;
+    if (a.use_lds_hist && !getenv("CAMMIQ_LDS_HIST_MAX")) {
+        auto resident = [&](bool hist) {
+            const size_t per_cu = (160u * 1024u) / smem_bytes(kFastR, kFastCAP, a, hist);
+            return per_cu < (size_t)CQ_MAX_BLOCKS_PER_CU ? per_cu : (size_t)CQ_MAX_BLOCKS_PER_CU;
+        };
+        if (resident(true) < resident(false)) a.use_lds_hist = 0;
+    }
     hipError_t e;
     // LDS above the 64 KiB default needs an explicit opt-in (large G)
     e = hipFuncSetAttribute((const void *)classify_kernel<kFastR, kFastCAP, false>,
