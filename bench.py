@@ -201,6 +201,13 @@ def main():
                     uid = [cq.comm_unique_id() if rank == 0 else None]
                     tdist.broadcast_object_list(uid, src=0)
                     comm = cq.Comm(ix, uid[0], rank, world)
+                    # pre-flight: a 16-word block of ones must come back as 16 x world from the library's collective
+                    probe_t = torch.ones(16, dtype=torch.int64, device="cuda")
+                    probe_r = torch.ones(8, dtype=torch.int32, device="cuda")
+                    comm.allreduce_counts(probe_t.data_ptr(), 16, probe_r.data_ptr(), 8, stream)
+                    torch.cuda.synchronize()
+                    if int(probe_t.sum().item()) != 16 * world or int(probe_r.sum().item()) != 8 * world:
+                        raise RuntimeError("cq_counts_allreduce pre-flight returned a wrong sum")
                     reduce_how = "cq_counts_allreduce (RCCL, libcammiq_hip.so)"
                 except Exception as e:   # keep the scaling run alive and say so in the record
                     comm = None

@@ -93,9 +93,9 @@ struct cq_index {
         uint32_t *h_packed = nullptr, *d_packed = nullptr;   // pinned host / device rows
         uint8_t *h_lens = nullptr, *d_lens = nullptr;
         size_t cap_words_h = 0, cap_reads_h = 0, cap_words_d = 0, cap_reads_d = 0;
-        hipEvent_t copied = nullptr, done = nullptr;
+        hipEvent_t copied = nullptr, copied_lens = nullptr, done = nullptr;
     } slot[2];
-    hipStream_t s_copy = nullptr, s_comp = nullptr;
+    hipStream_t s_copy = nullptr, s_copy2 = nullptr, s_comp = nullptr;   // rows | lengths (their own DMA queue) | kernels
     uint64_t *d_ctr = nullptr; size_t ctr_cap = 0;
     uint32_t *d_rc = nullptr; size_t rc_cap = 0;
     void *h_bounce[2] = {nullptr, nullptr};
@@ -149,10 +149,12 @@ void release_device(cq_index *ix)
         if (sl.d_packed) (void)hipFree(sl.d_packed);
         if (sl.d_lens) (void)hipFree(sl.d_lens);
         if (sl.copied) (void)hipEventDestroy(sl.copied);
+        if (sl.copied_lens) (void)hipEventDestroy(sl.copied_lens);
         if (sl.done) (void)hipEventDestroy(sl.done);
     }
     for (void *b : ix->h_bounce) if (b) (void)hipHostFree(b);
     if (ix->s_copy) (void)hipStreamDestroy(ix->s_copy);
+    if (ix->s_copy2) (void)hipStreamDestroy(ix->s_copy2);
     if (ix->s_comp) (void)hipStreamDestroy(ix->s_comp);
     if (ix->d_ctr) (void)hipFree(ix->d_ctr);
     if (ix->d_rc) (void)hipFree(ix->d_rc);
@@ -569,6 +571,7 @@ int slot_reserve(cq_index::Slot &sl, uint64_t n, uint32_t sw, bool host_too)
         sl.cap_reads_h = n;
     }
     if (!sl.copied) CQ_HIP(hipEventCreateWithFlags(&sl.copied, hipEventDisableTiming));
+    if (!sl.copied_lens) CQ_HIP(hipEventCreateWithFlags(&sl.copied_lens, hipEventDisableTiming));
     if (!sl.done) CQ_HIP(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
     return CQ_OK;
 }
@@ -608,6 +611,7 @@ int classify_range(cq_index *ix, int mode, const Feed &f, uint64_t lo, uint64_t 
     const cq::FlatImage &img = ix->H->img;
     CQ_HIP(hipSetDevice(ix->device));
     if (!ix->s_copy) CQ_HIP(hipStreamCreateWithFlags(&ix->s_copy, hipStreamNonBlocking));
+    if (!ix->s_copy2) CQ_HIP(hipStreamCreateWithFlags(&ix->s_copy2, hipStreamNonBlocking));
     if (!ix->s_comp) CQ_HIP(hipStreamCreateWithFlags(&ix->s_comp, hipStreamNonBlocking));
     const uint64_t cw = cq_counter_words(n_genomes);
     const uint64_t nl = img.n_leaves[0] + img.n_leaves[1];
@@ -661,9 +665,13 @@ int classify_range(cq_index *ix, int mode, const Feed &f, uint64_t lo, uint64_t 
             src_lens = f.lens + c0;
         }
         CQ_HIP(hipMemcpyAsync(sl.d_packed, src_rows, (size_t)n * sw * 4, hipMemcpyHostToDevice, ix->s_copy));
-        CQ_HIP(hipMemcpyAsync(sl.d_lens, src_lens, n, hipMemcpyHostToDevice, ix->s_copy));
         CQ_HIP(hipEventRecord(sl.copied, ix->s_copy));
+        // the small copy of the lengths goes down its own queue: behind the rows it would put a bubble between
+        // every two large transfers
+        CQ_HIP(hipMemcpyAsync(sl.d_lens, src_lens, n, hipMemcpyHostToDevice, ix->s_copy2));
+        CQ_HIP(hipEventRecord(sl.copied_lens, ix->s_copy2));
         CQ_HIP(hipStreamWaitEvent(ix->s_comp, sl.copied, 0));
+        CQ_HIP(hipStreamWaitEvent(ix->s_comp, sl.copied_lens, 0));
         rc = cq_query_device(ix, mode, sl.d_packed, sl.d_lens, n, sw, (uint32_t)max_len, n_genomes, ix->d_ctr, d_rc,
                              ix->s_comp);
         if (rc != CQ_OK) break;

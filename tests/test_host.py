@@ -348,3 +348,25 @@ def test_header_is_plain_c99_and_the_abi_works_from_c(tmp_path):
     ix = cq.Index(g["pu"], g["pd"], device=-1)
     assert r.stdout.split() == ["ok", "hash_len", str(ix.hash_len), "leaves", f"{ix.n_leaves[0]}+{ix.n_leaves[1]}",
                                 "keys", str(ix.info.n_keys)]
+
+
+def test_pack_read_single_row_equals_batch_packer():
+    """cq_pack_read (one sequence line at a time, what the CLI's FASTQ loader calls from its threads) gives the
+    rows and lengths of cq_pack_reads; hash_len = 1 leaves short reads to the kernel."""
+    import ctypes as C
+    reads = [b"ACGT" * 8, b"acgtACGTTTGA" * 3, b"ACGTN" * 7, b"AC", b"T" * 255, b"G" * 100, b"ACGT\xe6ACGT" * 4]
+    b, o = synth.concat_reads(reads)
+    h = 26
+    packed, lens, _ = cq.pack_reads(b, o, h)
+    sw = packed.shape[1]
+    L = binding.lib()
+    for i, r in enumerate(reads):
+        row = np.full(sw, 0xDEADBEEF, np.uint32)
+        ln = C.c_uint8(77)
+        buf = np.frombuffer(r, np.uint8)
+        assert L.cq_pack_read(buf.ctypes.data_as(C.c_void_p), len(r), h, sw, row.ctypes.data_as(C.c_void_p), C.byref(ln)) == 0
+        assert ln.value == lens[i] and np.array_equal(row, packed[i]), i
+        assert L.cq_pack_read(buf.ctypes.data_as(C.c_void_p), len(r), 1, sw, row.ctypes.data_as(C.c_void_p), C.byref(ln)) == 0
+        ok = all(c in b"ACGTacgt" for c in r) and 1 <= len(r) <= 255
+        assert ln.value == (len(r) if ok else 0)
+    assert L.cq_pack_read(None, 5, 1, sw, None, None) == -1

@@ -89,6 +89,7 @@ void run(const char *name, K kern, uint32_t *out, int n_cus, double mhz, int per
         const double instr_per_simd = (double)iters * 64 * per_instr * w;   // wave-instructions one SIMD issued
         printf("%-12s %d waves/SIMD: %7.3f ms  -> %.2f cycles per wave-instruction per SIMD (at %.0f MHz)\n", name, w, ms,
                cyc / instr_per_simd, mhz);
+        fflush(stdout);
     }
 }
 
@@ -110,8 +111,12 @@ int main()
     run("v_bfrev", k_bfrev, out, n, mhz, 1);
     run("v_mul_u24", k_mul24, out, n, mhz, 1);
     run("v_mul_lo_u32", k_mul, out, n, mhz, 1);
-    run("v_lshrrev_b64", k_shr64, out, n, mhz, 1);
-    run("s_or_b64", k_sor, out, n, mhz, 1);
-    run("v_cmp+s_or", k_cmp_sor, out, n, mhz, 2);
+    // k_shr64 / k_sor / k_cmp_sor are compiled but not run by default: one of them did not finish within the tool's
+    // time limit on the pool's boxes (the runs in profiles/r02_valu_issue_cost.txt end after v_mul_lo_u32)
+    if (getenv("VALU_BENCH_ALL")) {
+        run("v_lshrrev_b64", k_shr64, out, n, mhz, 1);
+        run("s_or_b64", k_sor, out, n, mhz, 1);
+        run("v_cmp+s_or", k_cmp_sor, out, n, mhz, 2);
+    }
     return 0;
 }
