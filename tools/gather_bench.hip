@@ -61,13 +61,42 @@ void run(const uint4 *tab, size_t bytes, uint32_t *out, int blocks_per_cu)
 // gather_bench            the round-1 sweep (2 MiB .. 8 GiB)
 // gather_bench MIB        one table size (MiB), W = 16 and 64 at 4 / 6 / 8 blocks per CU: the ceiling
 //                         bench.py's roofline.gather_ceiling_frac is measured against for that table
+// Table from the virtual-memory API: physical chunks of chunk_mb MiB (each one allocation, hence contiguous), mapped
+// back to back into one reserved range -- to see whether larger physically contiguous pieces buy TLB reach.
+static uint4 *vmm_alloc(size_t bytes, size_t chunk_mb)
+{
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = 0;
+    size_t gran = 0;
+    CK(hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended));
+    size_t chunk = chunk_mb << 20;
+    chunk = (chunk + gran - 1) / gran * gran;
+    const size_t n = (bytes + chunk - 1) / chunk;
+    void *base = nullptr;
+    CK(hipMemAddressReserve(&base, n * chunk, chunk, nullptr, 0));
+    for (size_t i = 0; i < n; i++) {
+        hipMemGenericAllocationHandle_t h;
+        CK(hipMemCreate(&h, chunk, &prop, 0));
+        CK(hipMemMap((char *)base + i * chunk, chunk, 0, h, 0));
+    }
+    hipMemAccessDesc acc = {};
+    acc.location = prop.location;
+    acc.flags = hipMemAccessFlagsProtReadWrite;
+    CK(hipMemSetAccess(base, n * chunk, &acc, 1));
+    printf("vmm: granularity %zu KiB, %zu chunks of %zu MiB at %p\n", gran >> 10, n, chunk >> 20, base);
+    return (uint4 *)base;
+}
+
 int main(int argc, char **argv)
 {
     if (argc > 1) {
         const size_t bytes = (size_t)atoll(argv[1]) << 20;
         uint4 *tab;
         uint32_t *out;
-        CK(hipMalloc(&tab, bytes));
+        if (argc > 2) tab = vmm_alloc(bytes, (size_t)atoll(argv[2]));   // gather_bench MIB CHUNK_MIB
+        else CK(hipMalloc(&tab, bytes));
         CK(hipMalloc(&out, 4));
         CK(hipMemset(tab, 1, bytes));
         for (int occ : {4, 6, 8}) {
