@@ -664,14 +664,8 @@ int classify_range(cq_index *ix, int mode, const Feed &f, uint64_t lo, uint64_t 
             src_rows = f.packed + (size_t)c0 * sw;
             src_lens = f.lens + c0;
         }
-        // rows: CAMMIQ_H2D_SPLIT=1 (experiment) sends the two halves of a chunk down two queues at once
-        static const bool split = getenv("CAMMIQ_H2D_SPLIT") != nullptr;
-        const size_t row_bytes = (size_t)n * sw * 4, half = split ? (row_bytes / 2) & ~(size_t)255 : row_bytes;
-        CQ_HIP(hipMemcpyAsync(sl.d_packed, src_rows, half, hipMemcpyHostToDevice, ix->s_copy));
+        CQ_HIP(hipMemcpyAsync(sl.d_packed, src_rows, (size_t)n * sw * 4, hipMemcpyHostToDevice, ix->s_copy));
         CQ_HIP(hipEventRecord(sl.copied, ix->s_copy));
-        if (half < row_bytes)
-            CQ_HIP(hipMemcpyAsync((char *)sl.d_packed + half, (const char *)src_rows + half, row_bytes - half, hipMemcpyHostToDevice,
-                                  ix->s_copy2));
         // the small copy of the lengths goes down its own queue: behind the rows it would put a bubble between
         // every two large transfers
         CQ_HIP(hipMemcpyAsync(sl.d_lens, src_lens, n, hipMemcpyHostToDevice, ix->s_copy2));
