@@ -20,7 +20,8 @@
 //     one pass over the hash words and its low words two 64-bit pieces of the row;
 //   * the merged unique+doubly-unique table is addressed by the minimizer (cq_device.h):
 //     forward and reverse h-mer of a window share one 64-byte bucket, and so do runs of
-//     neighbouring windows -- inside a lane they reuse the loaded registers, across lanes the
+//     neighbouring windows -- a lane loads ONE 16-byte key_lo[4] per run of equal minimizer
+//     among its windows, all of its loads issued before the single wait; across lanes the
 //     memory system serves identical loads with one HBM access (reference: four robin_hood
 //     lookups per window position, query.cpp:487-492,513-518);
 //   * the hot loop only DETECTS (low-word compare of the four slots); the few windows
@@ -28,8 +29,9 @@
 //     list, which the wave drains with full lanes: exact 64-bit compare, bucket chain,
 //     trie walk -- the divergent, dependent work never stalls the probe stream;
 //   * hits are gathered per read in LDS; one lane per read then de-duplicates them and
-//     applies the decision rule; per-genome counters are reduced in LDS and flushed with
-//     one global atomic per touched genome per workgroup; rcount uses global atomics.
+//     applies the decision rule; per-genome counters are reduced in LDS (cnt_u | cnt_d in
+//     the halves of one word, when that costs no resident workgroup) and flushed with one
+//     global atomic per touched genome per workgroup; rcount uses global atomics.
 //
 // Integer only; MFMA is deliberately unused.
 #include <hip/hip_runtime.h>
