@@ -3,6 +3,7 @@
 // Built and run by tests/test_sanitize.py:
 //   g++ -std=c++17 -O1 -g -fsanitize=address,undefined -fno-sanitize-recover=all ...
 // usage: host_sanitize index_u.bin1 [index_d.bin2|-] reads.txt
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
@@ -10,6 +11,9 @@
 #include <vector>
 
 #include "../../cammiq_amd/csrc/cq_index.hpp"
+#include "../../include/cammiq_glue.hpp"
+
+struct MetaGenome { uint64_t read_cnts_u = 0, read_cnts_d = 0; uint32_t glength = 0, nus = 0, nds = 0; };
 
 int main(int argc, char **argv)
 {
@@ -46,6 +50,22 @@ int main(int argc, char **argv)
     std::vector<uint8_t> lens(n + 1);
     uint64_t sk = 0;
     rc = cq_pack_reads(bases.data(), offs.data(), n, img.hash_len, sw, packed.data(), lens.data(), &sk);
+    // the same reads once more at the tight stride of each read, one row at a time (cq_pack_read: what the CLI's FASTQ
+    // loader calls), rows allocated exactly so that a write past a row's end is caught
+    for (uint64_t r = 0; r < n; r++) {
+        const uint64_t len = offs[r + 1] - offs[r];
+        const uint32_t w = cq_pack_stride_words(len > 255 ? 255 : (uint32_t)len);
+        std::vector<uint32_t> row(w);
+        uint8_t lo = 7;
+        if (cq_pack_read(bases.data() + offs[r], (uint32_t)(len > 0xFFFFFFFFull ? 0 : len), 1, w, row.data(), &lo) != CQ_OK) { printf("PACK_READ FAILED\n"); return 1; }
+        if (lo != lens[r] && !(lens[r] == 0 && len < img.hash_len)) { printf("PACK_READ LEN %u vs %u\n", lo, lens[r]); return 1; }
+    }
+    // meta files next to index_u (glue header): whatever is there -- present, absent or damaged -- must parse cleanly
+    {
+        std::vector<MetaGenome> genomes(std::min<uint64_t>((uint64_t)img.max_refid + 2, 100000));   // a damaged index may carry any refID
+        const char *msg = cq_glue::load_genome_meta(cq_glue::index_dir(argv[1]), genomes, true);
+        printf("meta %s", msg ? msg : "loaded\n");
+    }
     printf("ok leaves %zu+%zu keys %llu nodes %zu found %llu reads %llu skipped %llu rc %d\n", u.leaves.size(), d.leaves.size(),
            (unsigned long long)img.n_keys, img.nodes.size(), (unsigned long long)found, (unsigned long long)n,
            (unsigned long long)sk, rc);
