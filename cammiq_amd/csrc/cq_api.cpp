@@ -663,6 +663,12 @@ int classify_range(cq_index *ix, int mode, const Feed &f, uint64_t lo, uint64_t 
         } else {
             src_rows = f.packed + (size_t)c0 * sw;
             src_lens = f.lens + c0;
+            // the lane grid is sized by the longest read: take it from the lengths themselves (a max_len that is too
+            // small would silently drop windows), and refuse lengths the rows cannot hold
+            uint32_t longest = 0;
+            for (uint64_t r = 0; r < n; r++) longest = std::max<uint32_t>(longest, src_lens[r]);
+            if (longest > sw * 16u) { rc = fail(CQ_ERR_ARG, "cq_query_packed: a length exceeds 16 x stride_words bases"); break; }
+            max_len = std::max<uint64_t>(max_len, longest);
         }
         CQ_HIP(hipMemcpyAsync(sl.d_packed, src_rows, (size_t)n * sw * 4, hipMemcpyHostToDevice, ix->s_copy));
         CQ_HIP(hipEventRecord(sl.copied, ix->s_copy));

@@ -153,7 +153,8 @@ int cq_query(cq_index *idx, int mode, const uint8_t *bases, const uint64_t *offs
  * previous chunk is being classified, counters come back at the end -- H2D + kernels + D2H, the
  * bracket of the reference's "Time for query" (query.cpp:459,645-647) without the host-side
  * packing.  Buffers from cq_host_alloc (pinned) make both directions run at link speed; pageable
- * memory works too, slower.
+ * memory works too, slower.  max_len is a hint (0 = unknown): the longest length found in `lens` is what
+ * sizes the work; a length above 16 * stride_words is CQ_ERR_ARG.
  */
 int cq_query_packed(cq_index *idx, int mode, const uint32_t *packed, const uint8_t *lens,
                     uint64_t n_reads, uint32_t stride_words, uint32_t max_len, uint32_t n_genomes,

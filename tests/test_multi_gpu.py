@@ -74,6 +74,15 @@ def test_query_packed_equals_query_and_kernel_times(tmp_path):
         assert_same(got, g["exp"]["p"], "packed, pinned")
     fast, slow = ix.last_kernel_times()
     assert fast > 0 and slow >= 0 and abs(ix.last_kernel_ms() - (fast + slow)) < 1e-3
+    # max_len is only a hint: unknown (0) or too small, the lengths themselves size the work
+    for hint in (0, 30):
+        assert_same(ix.query_packed(packed, lens, hint, g["G"]), g["exp"]["p"], f"hint {hint}")
+    bad = lens.copy()
+    bad[5] = 255
+    narrow = np.ascontiguousarray(packed[:, :4])            # rows of 4 words hold 64 bases
+    with pytest.raises(cq.CammiqError) as e:
+        ix.query_packed(narrow, bad, 64, g["G"])
+    assert e.value.code == -1
 
 
 def test_large_rcount_comes_back_through_the_bounce_buffers(tmp_path):
