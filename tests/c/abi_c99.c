@@ -43,6 +43,20 @@ int main(int argc, char **argv)
     if (cq_pack_stride_words(32) != 2 || cq_pack_stride_words(100) != 7) return 12;
     if (cq_pack_reads(read, offs, 1, info.hash_len, 4, packed, &len, &skipped) != CQ_OK) return 13;
     if (len != 32 || skipped != 0 || packed[0] != 0x1B1B1B1Bu) return 14;   /* ACGT = 00 01 10 11, MSB first */
+    {   /* round-2 entry points that need no GPU: single-row packer, sharding rule, packed query on a host-only handle */
+        uint32_t row[2] = {0, 0};
+        uint8_t l2 = 0;
+        uint64_t lo = 9, hi = 9;
+        uint64_t c1[8] = {0}, c2[8] = {0};
+        cq_counts c;
+        if (cq_pack_read(read, 32, 1, 2, row, &l2) != CQ_OK || l2 != 32 || row[0] != 0x1B1B1B1Bu || row[1] != 0x1B1B1B1Bu) return 15;
+        if (cq_shard_range(10, 1, 3, &lo, &hi) != CQ_OK || lo != 3 || hi != 6) return 16;
+        if (cq_shard_range(10, 3, 3, &lo, &hi) != CQ_ERR_ARG) return 17;
+        memset(&c, 0, sizeof c);
+        c.cnt_u = c1; c.cnt_d = c2;
+        if (cq_query_packed(ix, CQ_MODE_SC, packed, &len, 1, 4, 32, 4, &c) != CQ_ERR_NO_DEVICE) return 18;
+        if (cq_multi_size(NULL) != 0 || cq_multi_index(NULL, 0) != NULL) return 19;
+    }
     printf("ok hash_len %u leaves %llu+%llu keys %llu\n", info.hash_len, (unsigned long long)info.n_leaves[0],
            (unsigned long long)info.n_leaves[1], (unsigned long long)info.n_keys);
     free(leaves);
