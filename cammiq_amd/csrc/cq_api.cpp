@@ -87,14 +87,14 @@ struct cq_index {
     uint32_t pair_cap = 0;          // slots, power of two
     hipEvent_t ev0 = nullptr, ev_mid = nullptr, ev1 = nullptr;   // start | fast kernel done | slow kernel done
     bool ev_valid = false;
-    // host-fed paths (cq_query, cq_query_packed): two staging slots so that packing chunk c+1 on
-    // the CPU, its H2D copy and the classify kernel of chunk c overlap
+    // host-fed paths (cq_query, cq_query_packed): three staging slots so that packing chunk c+1 on
+    // the CPU, its H2D copy and the classify kernel of chunk c overlap with slack for host jitter
     struct Slot {
         uint32_t *h_packed = nullptr, *d_packed = nullptr;   // pinned host / device rows
         uint8_t *h_lens = nullptr, *d_lens = nullptr;
         size_t cap_words_h = 0, cap_reads_h = 0, cap_words_d = 0, cap_reads_d = 0;
         hipEvent_t copied = nullptr, copied_lens = nullptr, done = nullptr;
-    } slot[2];
+    } slot[3];   // three: the host may enqueue the copy of chunk c+1 while kernel c-1 is still running
     hipStream_t s_copy = nullptr, s_copy2 = nullptr, s_comp = nullptr;   // rows | lengths (their own DMA queue) | kernels
     uint64_t *d_ctr = nullptr; size_t ctr_cap = 0;
     uint32_t *d_rc = nullptr; size_t rc_cap = 0;
@@ -601,7 +601,7 @@ int query_checks(const cq_index *ix, int mode, uint32_t n_genomes, const cq_coun
 
 // Classify reads [lo, hi) of `f` on ix's device into the handle's own counter block (d_ctr) and
 // rcount array (d_rc), both zeroed first: resetCounters + query64_* (query.cpp:1820-1840, 458-1080).
-// Chunks of 2 M reads alternate between two staging slots:
+// Chunks of 2 M reads rotate over three staging slots:
 //   CPU   pack(c+1) ........ pack(c+2) ........          (ASCII feed only)
 //   copy           H2D(c+1) ...........H2D(c+2)
 //   comp  kernel(c) ........ kernel(c+1) .......
@@ -637,7 +637,7 @@ int classify_range(cq_index *ix, int mode, const Feed &f, uint64_t lo, uint64_t 
     int rc = CQ_OK;
     uint64_t c = 0;
     for (uint64_t c0 = lo; c0 < hi && rc == CQ_OK; c0 += kChunk, c++) {
-        cq_index::Slot &sl = ix->slot[c & 1];
+        cq_index::Slot &sl = ix->slot[c % 3];
         const uint64_t n = std::min(kChunk, hi - c0);
         uint64_t max_len = f.max_len;
         uint32_t sw = f.sw;
