@@ -105,23 +105,11 @@ std::vector<Genome> load_map(const std::string &fn)
 // which is what cq_query_packed takes -- the ASCII reads are never copied (--fastq_stats keeps an
 // ASCII pass 2 for its digest).  The output buffers are not initialised first (their pages are
 // first touched by the copying threads).
-// Page-locked when the GPU runtime hands it out (cq_host_alloc: transfers then run at link speed), plain memory
-// otherwise (no device: the run ends at the classify call with the library's message anyway).
-struct HostFree { bool pinned = false; void operator()(void *p) const { if (pinned) cq_host_free(p); else free(p); } };
-template <class T> using HostBuf = std::unique_ptr<T[], HostFree>;
-template <class T> HostBuf<T> host_buf(size_t n)
-{
-    void *p = nullptr;
-    const size_t bytes = (n ? n : 1) * sizeof(T);
-    if (cq_host_alloc(&p, bytes) == CQ_OK && p) return HostBuf<T>((T *)p, HostFree{true});
-    return HostBuf<T>((T *)malloc(bytes), HostFree{false});
-}
-
 struct Reads {
     std::unique_ptr<uint8_t[]> bases;   // ASCII (--fastq_stats only)
     std::unique_ptr<uint64_t[]> offs;   // n_reads + 1
-    HostBuf<uint32_t> packed;           // 2-bit rows, stride sw words (queries: the ASCII reads are never materialised)
-    HostBuf<uint8_t> lens;
+    std::unique_ptr<uint32_t[]> packed; // 2-bit rows, stride sw words (queries: the ASCII reads are never materialised)
+    std::unique_ptr<uint8_t[]> lens;
     uint32_t sw = 1, max_len = 0;
     size_t n_reads = 0, n_bases = 0;
 };
@@ -191,9 +179,8 @@ void read_fastq(const std::string &fn, size_t min_l, Reads &out, bool pack = fal
     out.sw = cq_pack_stride_words(out.max_len);
     const uint32_t sw = out.sw;
     if (pack) {
-        out.packed = host_buf<uint32_t>(out.n_reads * sw + 1);
-        out.lens = host_buf<uint8_t>(out.n_reads + 1);
-        if (!out.packed || !out.lens) die("Out of memory while reading %s.\n", fn.c_str());
+        out.packed.reset(new uint32_t[out.n_reads * sw + 1]);
+        out.lens.reset(new uint8_t[out.n_reads + 1]);
     } else {
         out.bases.reset(new uint8_t[out.n_bases ? out.n_bases : 1]);
         out.offs.reset(new uint64_t[out.n_reads + 1]);
@@ -444,10 +431,7 @@ int main(int argc, char **argv)
     }
 
     std::vector<uint64_t> cu(G + 1), cd(G + 1), pc(1 << 16);
-    std::vector<uint32_t> pa(1 << 16), pb(1 << 16);
-    const size_t n_ru = info.n_leaves[0], n_rd = info.n_leaves[1];
-    HostBuf<uint32_t> ru = host_buf<uint32_t>(n_ru), rd = host_buf<uint32_t>(n_rd);   // pleafNode::rcount, decode order
-    if (!ru || !rd) die("Out of memory.\n");
+    std::vector<uint32_t> ru(info.n_leaves[0]), rd(info.n_leaves[1]), pa(1 << 16), pb(1 << 16);
     for (size_t f = 0; f < fq_names.size(); f++) {
         Reads fq = next_fq.get();
         if (f + 1 < fq_names.size()) next_fq = parse_async(f + 1);
@@ -461,7 +445,7 @@ int main(int argc, char **argv)
         for (;;) {
             memset(&c, 0, sizeof c);
             c.cnt_u = cu.data(); c.cnt_d = cd.data();
-            c.rcount_u = n_ru ? ru.get() : nullptr; c.rcount_d = n_rd ? rd.get() : nullptr;
+            c.rcount_u = ru.empty() ? nullptr : ru.data(); c.rcount_d = rd.empty() ? nullptr : rd.data();
             c.pair_a = pa.data(); c.pair_b = pb.data(); c.pair_cnt = pc.data(); c.pair_cap = pc.size();
             rc = mx ? cq_multi_query_packed(mx, qmode, fq.packed.get(), fq.lens.get(), fq.n_reads, fq.sw, fq.max_len, G, &c)
                     : cq_query_packed(ix, qmode, fq.packed.get(), fq.lens.get(), fq.n_reads, fq.sw, fq.max_len, G, &c);

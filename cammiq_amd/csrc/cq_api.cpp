@@ -415,7 +415,7 @@ int cq_host_alloc(void **p, size_t bytes)
 {
     if (!p) return fail(CQ_ERR_ARG, "cq_host_alloc: NULL argument");
     *p = nullptr;
-    CQ_HIP(hipHostMalloc(p, bytes ? bytes : 1, hipHostMallocPortable));   // usable from every device (cq_multi_*)
+    CQ_HIP(hipHostMalloc(p, bytes ? bytes : 1, hipHostMallocDefault));
     return CQ_OK;
 }
 
