@@ -49,7 +49,7 @@ try:
     out = os.path.join(wdir, "out.tsv")
     def run_cli(extra):
         t0 = time.time()
-        r = subprocess.run([os.path.join(ROOT, "cammiq_amd", "cammiq"), "--query", "--read_cnts", "-f",
+        r = subprocess.run([os.environ.get("CAMMIQ_CLI", os.path.join(ROOT, "cammiq_amd", "cammiq")), "--query", "--read_cnts", "-f",
                             os.path.join(wdir, "genome_map.out"), "-i", pu, "-q", fq, "-o", out] + extra,
                            capture_output=True, text=True, env=dict(os.environ, CAMMIQ_LOAD_TIMING="1"))
         wall = time.time() - t0
