@@ -326,6 +326,8 @@ void drop_host_image(HostIndex &H)
     std::vector<uint32_t>().swap(H.img.leaf_r2);
 }
 
+void warm_workspace(cq_index *ix);   // below, next to the host-fed pipeline it prepares
+
 double table_budget(int device)
 {
     size_t free_b = 0, total_b = 0;
@@ -357,6 +359,8 @@ int cq_index_load(const char *path_u, const char *path_d, int device, cq_index *
         lt.lap("upload");
         if (rc != CQ_OK) { release_device(ix); delete ix; return rc; }
         drop_host_image(*ix->H);
+        warm_workspace(ix);
+        lt.lap("workspace");
     }
     *out = ix;
     return CQ_OK;
@@ -574,6 +578,29 @@ int slot_reserve(cq_index::Slot &sl, uint64_t n, uint32_t sw, bool host_too)
     if (!sl.copied_lens) CQ_HIP(hipEventCreateWithFlags(&sl.copied_lens, hipEventDisableTiming));
     if (!sl.done) CQ_HIP(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
     return CQ_OK;
+}
+
+// Everything a first query would otherwise allocate while the clock of "Time for query" runs (about 25 ms of
+// hipMalloc / hipHostMalloc / stream and event creation for a 10 M-read FASTQ): streams, events, the two bounce
+// buffers, rcount, a counter block for up to 16 383 genomes, the slow-path list and the three device slots of one
+// 2 M-read chunk of 128-base rows.  Larger needs grow on demand as before.  Failures here are not errors.
+void warm_workspace(cq_index *ix)
+{
+    if (ix->device < 0 || hipSetDevice(ix->device) != hipSuccess) return;
+    const cq::FlatImage &img = ix->H->img;
+    if (!ix->s_copy) (void)hipStreamCreateWithFlags(&ix->s_copy, hipStreamNonBlocking);
+    if (!ix->s_copy2) (void)hipStreamCreateWithFlags(&ix->s_copy2, hipStreamNonBlocking);
+    if (!ix->s_comp) (void)hipStreamCreateWithFlags(&ix->s_comp, hipStreamNonBlocking);
+    for (auto &sl : ix->slot) (void)slot_reserve(sl, kChunk, 8, false);
+    for (int b = 0; b < 2; b++) {
+        if (!ix->h_bounce[b] && hipHostMalloc(&ix->h_bounce[b], kBounce, hipHostMallocDefault) != hipSuccess) ix->h_bounce[b] = nullptr;
+        if (!ix->ev_bounce[b]) (void)hipEventCreateWithFlags(&ix->ev_bounce[b], hipEventDisableTiming);
+    }
+    const uint64_t nl = img.n_leaves[0] + img.n_leaves[1], cw = cq_counter_words(16383);
+    if (nl && !ix->d_rc && hipMalloc((void **)&ix->d_rc, nl * 4) == hipSuccess) ix->rc_cap = nl;
+    if (!ix->d_ctr && hipMalloc((void **)&ix->d_ctr, cw * 8) == hipSuccess) ix->ctr_cap = cw;
+    if (!ix->d_ovf_list && hipMalloc((void **)&ix->d_ovf_list, kChunk * sizeof(uint32_t)) == hipSuccess) ix->ovf_cap = kChunk;
+    (void)hipGetLastError();
 }
 
 // Where the reads of a host-fed query come from: ASCII as FqReader::readFastq leaves them
@@ -943,6 +970,7 @@ int cq_multi_load(const char *path_u, const char *path_d, const int *devices, in
     for (int i = 0; i < n_dev; i++)
         if (rcs[i] != CQ_OK) { cq_multi_free(m); return fail(rcs[i], errs[i]); }
     drop_host_image(*H);
+    for (int i = 0; i < n_dev; i++) warm_workspace(m->ix[i]);
     // Handles on the same device form a group (rehearsal on a box with fewer GPUs than shards): they
     // are summed by a device kernel; the group leaders -- distinct devices -- meet in the RCCL all-reduce.
     m->leader_of.assign(n_dev, 0);
