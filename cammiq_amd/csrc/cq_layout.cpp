@@ -232,8 +232,10 @@ int build_image(const DecodedTable &u, const DecodedTable &d, double keys_per_bu
 
     // ---- entries of both tables, sorted by (home bucket, key, file order)
     const uint64_t nb_u = u.bucket_key.size(), nb_d = d.bucket_key.size();
-    if (keys_per_bucket <= 0.1) keys_per_bucket = 1.5;
-    uint64_t nbk = (uint64_t)((double)(nb_u + nb_d) / keys_per_bucket) + 1;
+    if (!(keys_per_bucket > 0.0)) keys_per_bucket = 1.5;
+    const double want = (double)(nb_u + nb_d) / keys_per_bucket;
+    if (!(want < 4294967295.0)) { err = "table would exceed 2^32 buckets"; return CQ_ERR_LIMIT; }
+    uint64_t nbk = (uint64_t)want + 1;
     if (nbk < 16) nbk = 16;
     if (nbk + CQ_SPILL_TAIL >= 0xFFFFFFFFull) { err = "table would exceed 2^32 buckets"; return CQ_ERR_LIMIT; }
     img.n_buckets = nbk;
@@ -429,7 +431,42 @@ int build_image(const DecodedTable &u, const DecodedTable &d, double keys_per_bu
         overflowed += outs[p].overflowed;
         img.max_chain = std::max(img.max_chain, outs[p].max_chain);
     }
-    if (!outs[kParts - 1].left.empty()) { err = "spill tail exhausted while laying out the table"; return CQ_ERR_LIMIT; }
+    if (!outs[kParts - 1].left.empty()) {
+        // The carry outran the CQ_SPILL_TAIL buckets past the hash range (a very dense table whose last homes
+        // are crowded): the tail grows by what is still waiting.  Rare, so the table is simply copied.
+        const std::vector<Entry> &left = outs[kParts - 1].left;
+        const uint64_t extra = (left.size() + CQ_SLOTS_PER_BUCKET - 1) / CQ_SLOTS_PER_BUCKET;
+        const uint64_t old_alloc = img.n_buckets_alloc;
+        if (old_alloc + extra >= 0xFFFFFFFFull) { err = "table would exceed 2^32 buckets"; return CQ_ERR_LIMIT; }
+        std::unique_ptr<uint32_t[]> grown(new uint32_t[(old_alloc + extra) * CQ_BUCKET_WORDS]);
+        memcpy(grown.get(), img.table.get(), old_alloc * CQ_BUCKET_WORDS * sizeof(uint32_t));
+        img.table = std::move(grown);
+        img.n_buckets_alloc = old_alloc + extra;
+        img.table_words = img.n_buckets_alloc * CQ_BUCKET_WORDS;
+        size_t q = 0;
+        for (uint64_t b = old_alloc; b < img.n_buckets_alloc; b++) {   // the last old bucket already carries its overflow flag
+            uint32_t *bw = &img.table[b * CQ_BUCKET_WORDS];
+            for (int k = 0; k < CQ_SLOTS_PER_BUCKET; k++) {
+                bw[CQ_BW_KEY_LO + k] = bw[CQ_BW_KEY_HI + k] = 0xFFFFFFFFu;
+                bw[CQ_BW_VAL_U + k] = bw[CQ_BW_VAL_D + k] = 0u;
+            }
+            bw[CQ_BW_KEY_LO] = 0xFFFFFFFEu;
+            for (int k = 0; k < CQ_SLOTS_PER_BUCKET && q < left.size(); k++, q++) {
+                const Entry &e = left[q];
+                uint32_t lo = (uint32_t)e.key, hi32 = (uint32_t)(e.key >> 32);
+                if (k == 0) {
+                    if (lo & 1u) hi32 |= CQ_SLOT0_BIT0_IN_HI;
+                    lo &= ~1u;
+                }
+                bw[CQ_BW_KEY_LO + k] = lo;
+                bw[CQ_BW_KEY_HI + k] = hi32;
+                bw[CQ_BW_VAL_U + k] = e.val_u;
+                bw[CQ_BW_VAL_D + k] = e.val_d;
+                img.max_chain = std::max(img.max_chain, (uint32_t)(b - e.home) + 1);
+            }
+            if (q < left.size()) { bw[CQ_BW_KEY_LO] |= 1u; overflowed++; }
+        }
+    }
     img.n_overflowed = overflowed;
     st.lap("placement sweep");
     return CQ_OK;

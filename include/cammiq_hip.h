@@ -48,7 +48,7 @@ typedef enum cq_status {
     CQ_ERR_NO_DEVICE = -6, /* no HIP device / handle was loaded host-only */
     CQ_ERR_HIP = -7,       /* a HIP runtime call failed */
     CQ_ERR_NOMEM = -8,
-    CQ_ERR_LIMIT = -9,     /* more than 2^31-1 leaves / nodes, key longer than 255, pair arrays too small */
+    CQ_ERR_LIMIT = -9,     /* more than 2^31-1 leaves / nodes, 2^32 table buckets, key longer than 255, pair arrays too small */
     CQ_ERR_COMM = -10      /* an RCCL call failed (multi-GPU entry points) */
 } cq_status;
 

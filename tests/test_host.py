@@ -129,6 +129,19 @@ def test_load_errors(tmp_path):
     assert e.value.code == -3
 
 
+def test_bucket_index_limit_is_an_error_not_a_wrap(tmp_path, monkeypatch):
+    """Bucket numbers are 32-bit on the device: a table that would need 2^32 buckets or more is refused with
+    CQ_ERR_LIMIT and a message, before anything is allocated (the density knob makes a tiny index ask for one)."""
+    pu, pd = build_index(tmp_path, {b"ACGTACG": (1, 1), b"TTGTACG": (2, 1)}, {b"ACGTACGA": (1, 2, 1, 1)}, 6, "lim")
+    monkeypatch.setenv("CAMMIQ_KEYS_PER_BUCKET", "1e-10")
+    with pytest.raises(cq.CammiqError) as e:
+        cq.Index(pu, pd, device=-1)
+    assert e.value.code == -9 and "2^32 buckets" in str(e.value)
+    monkeypatch.setenv("CAMMIQ_KEYS_PER_BUCKET", "0.01")          # a sparse but legal table still loads and probes
+    ix = cq.Index(pu, pd, device=-1)
+    assert ix.info.n_table_buckets >= 300
+
+
 def test_no_cpu_fallback(tmp_path):
     """A host-only handle must refuse to classify; there is no CPU path to fall back to."""
     pu, pd = build_index(tmp_path, {b"ACGTACG": (1, 1)}, {}, 6, "n")
@@ -331,6 +344,31 @@ def test_parallel_layout_equals_serial_layout(name, tmp_path, monkeypatch):
             assert other[1] == ref[1], f"kpb {kpb}: parallel layout differs from the serial one"
     # the dense layouts really did spill (otherwise the fix-up path was not exercised)
     assert images["3.9"][0][0]["n_overflowed"] > images["1.0"][0][0]["n_overflowed"]
+
+
+def test_spill_tail_grows_when_a_dense_table_overruns_it(tmp_path, monkeypatch):
+    """World 20260038 of the randomised campaign: 3.9 keys per 4-slot bucket on a small table whose keys crowd
+    their minimizers' buckets.  The carry outruns the 64 buckets past the hash range; the tail grows by what is
+    left (it used to be CQ_ERR_LIMIT) and every key is still found, nothing else is."""
+    gen = synth.clade_genomes(20260038, 3, 2, 400, 0.08)
+    u, d = synth.select_markers(gen, 27, 27, keep_every=1, seed=20260038)
+    pu, pd = build_index(tmp_path, u, d, 26, name="dense", seed=20260038)
+    monkeypatch.setenv("CAMMIQ_KEYS_PER_BUCKET", "3.9")
+    ix = cq.Index(pu, pd, device=-1)
+    monkeypatch.setenv("CAMMIQ_KEYS_PER_BUCKET", "1.0")
+    sparse = cq.Index(pu, pd, device=-1)
+    i = ix.info_dict()
+    assert i["n_keys"] == sparse.info.n_keys
+    assert i["n_table_buckets"] > int(i["n_keys"] / 3.9) + 1 + 64, "the tail did not have to grow: pick another world"
+    hv = lambda key: int("".join("{:02b}".format(synth.SYM[c]) for c in key[:26]), 2)
+    present = {hv(k) for k in u} | {hv(k) for k in d}
+    assert len(present) == i["n_keys"]
+    for k in present:
+        cu, cd, chain = ix.probe(k)
+        assert (cu, cd) == sparse.probe(k)[:2] and (cu or cd) and 1 <= chain <= i["max_chain"]
+    rng = np.random.default_rng(2)
+    for k in rng.integers(0, 1 << 52, size=3000):
+        assert ix.probe(int(k))[:2] == (0, 0) or int(k) in present
 
 
 def test_header_is_plain_c99_and_the_abi_works_from_c(tmp_path):
