@@ -127,9 +127,81 @@ def _run_world(w, tmpdir):
     return len(good), len(u), len(d)
 
 
+def _draw_generator(seed):
+    """Worlds of the benchmark generator (csrc/cq_synth.cpp): realistic marker density, deep tries, shared blocks."""
+    r = random.Random(seed)
+    h = r.choice([12, 16, 17, 20, 24, 26, 26, 26, 31])
+    k = r.randint(h, 31)
+    me = r.choice([8, 20, 69, 69, 100])
+    G = r.choice([2, 5, 24, 80, 200])
+    markers = r.choice([3_000, 30_000, 150_000])
+    w = dict(seed=seed, kind="generator", h=h, k=k, lmax=k + r.choice([0, 3, 24, 40]), marker_every=me, n_genomes=G,
+             genome_len=max(markers * me // G, 600), frac_deep=r.choice([0.0, 0.07, 0.5]),
+             pair_share=r.choice([0.0, 0.1, 0.5]), block=r.choice([256, 2048, 8192]),
+             n_reads=r.choice([20_000, 60_000]), err=r.choice([0.0, 0.01, 0.05]), frac_random=r.choice([0.0, 0.1, 0.6]),
+             route=r.choice(["ascii", "packed", "multi", "multi_packed"]), env={})
+    w["rl"] = r.choice([h, 50, 75, 100, 100, 150, 250, 255])
+    w["rl"] = min(max(w["rl"], h), w["genome_len"])
+    if r.random() < 0.4:
+        w["env"]["CAMMIQ_MAX_SUB_PER_WAVE"] = str(r.choice([1, 7, 100]))
+    if r.random() < 0.3:
+        w["env"]["CAMMIQ_LDS_HIST_MAX"] = r.choice(["0", "1000000"])
+    if r.random() < 0.4:
+        w["env"]["CAMMIQ_KEYS_PER_BUCKET"] = r.choice(["0.5", "2.0", "3.2", "3.9"])
+    if r.random() < 0.3:
+        w["env"]["CAMMIQ_PAIR_SLOTS"] = "64"
+    return w
+
+
+def _run_generator_world(w, tmpdir):
+    from cammiq_amd import bigsynth
+    world = bigsynth.World(seed=w["seed"], n_genomes=w["n_genomes"], genome_len=w["genome_len"], k=w["k"], h=w["h"],
+                           lmax=w["lmax"], marker_every=w["marker_every"], frac_deep=w["frac_deep"],
+                           pair_share=w["pair_share"], block=w["block"])
+    pu = os.path.join(str(tmpdir), f"g{w['seed']}_u.bin1")
+    pd = os.path.join(str(tmpdir), f"g{w['seed']}_d.bin2") if w["pair_share"] else None
+    nu, nd = world.write_index(pu, pd)
+    G = w["n_genomes"]
+    b, o = world.reads(seed=w["seed"] + 1, n=w["n_reads"], length=w["rl"], err=w["err"], frac_random=w["frac_random"])
+    oi = oracle_lib.OracleIndex(pu, pd)
+    for kname in _KNOBS:
+        os.environ.pop(kname, None)
+    os.environ.update(w["env"])
+    try:
+        ix = cq.Multi(pu, pd, [0]) if w["route"].startswith("multi") else cq.Index(pu, pd, device=0)
+        for mode in (cq.MODE_P, cq.MODE_SC):
+            ref = oi.query(b, o, G, mode=mode, nthreads=8)
+            if w["route"].endswith("packed"):
+                packed, lens, sk = cq.pack_reads(b, o, w["h"])
+                assert sk == 0
+                got = ix.query_packed(packed, lens, w["rl"], G, mode=mode, pair_cap=1 << 18)
+            else:
+                got = ix.query(b, o, G, mode=mode, pair_cap=1 << 18)
+                assert got["nskipped"] == 0
+            assert_same(got, ref, f"mode={mode}", rcount=(mode == cq.MODE_P))
+            assert got["pairs"] == ref["pairs"], f"mode={mode}: pair map differs"
+        ix.close()
+    finally:
+        for kname in _KNOBS:
+            os.environ.pop(kname, None)
+    world.close()
+    for p in (pu, pd):
+        if p:
+            os.remove(p), os.remove(p + ".aux")
+    return w["n_reads"], nu, nd
+
+
 def test_fuzz_campaign(tmp_path):
-    budget = float(os.environ.get("CAMMIQ_FUZZ_SECONDS", "25"))
-    seed0 = int(os.environ.get("CAMMIQ_FUZZ_SEED", "20260000"))
+    _campaign(tmp_path, _draw, _run_world, 20260000, 25)
+
+
+def test_fuzz_campaign_generator_worlds(tmp_path):
+    _campaign(tmp_path, _draw_generator, _run_generator_world, 7260000, 20)
+
+
+def _campaign(tmp_path, _draw, _run_world, default_seed, default_seconds):
+    budget = float(os.environ.get("CAMMIQ_FUZZ_SECONDS", str(default_seconds)))
+    seed0 = int(os.environ.get("CAMMIQ_FUZZ_SEED", str(default_seed)))
     max_worlds = int(os.environ.get("CAMMIQ_FUZZ_WORLDS", "1000000"))
     log = open(os.environ["CAMMIQ_FUZZ_LOG"], "a") if os.environ.get("CAMMIQ_FUZZ_LOG") else None
     t0 = time.time()
