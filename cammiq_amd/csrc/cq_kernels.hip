@@ -9,7 +9,7 @@
 //     and staged in LDS (the "sliding window" lives there, not in registers of one thread);
 //     waves never synchronise with each other inside the main loop;
 //   * a pre-pass hashes every m-mer position of the tile once (canonical form, bijective
-//     32-bit hash) into LDS -- eight adjacent positions per lane, whose m-mers and reverse
+//     32-bit hash) into LDS -- eleven adjacent positions per lane, whose m-mers and reverse
 //     complements are bit-fields of one 64-bit piece of the row and of its reverse complement;
 //     a window's MINIMIZER is then the minimum over h-m+1 adjacent LDS words instead of
 //     h-m+1 hash evaluations per window;
@@ -79,7 +79,7 @@ constexpr uint32_t kWinPerLane = CQ_WIN_PER_LANE;
 #endif
 constexpr uint32_t kRunSlots = CQ_RUN_SLOTS;
 #ifndef CQ_PRE_POS
-#define CQ_PRE_POS 8       /* adjacent m-mer positions one lane hashes in the pre-pass (<= 16) */
+#define CQ_PRE_POS 11      /* adjacent m-mer positions one lane hashes in the pre-pass (<= 16): 100-bp reads, 8 per wave -> 8 x 8 groups = one full iteration */
 #endif
 constexpr uint32_t kPrePos = CQ_PRE_POS;
 constexpr int kWorkDrain = CQ_WORK_DRAIN;     // drain a wave's list once it holds this many items
@@ -536,7 +536,7 @@ classify_kernel(DevIndex ix, QueryArgs a)
         CQ_STAMP(0);   // staging
 
         // ---- pre-pass: hash the canonical m-mer at every base position, once.  A lane takes
-        // eight adjacent positions: their m-mers are bit-fields of one 64-bit piece of the row,
+        // kPrePos adjacent positions: their m-mers are bit-fields of one 64-bit piece of the row,
         // their reverse complements bit-fields of that piece's reverse complement.
         {
             const uint32_t gpr = (pmax + kPrePos - 1u) / kPrePos;  // position groups per read
@@ -770,15 +770,14 @@ classify_kernel(DevIndex ix, QueryArgs a)
     }
 }
 
-#ifndef CQ_FAST_R
-#define CQ_FAST_R 8
-#endif
 #ifndef CQ_FAST_CAP
 #define CQ_FAST_CAP 16
 #endif
-constexpr int kFastR = CQ_FAST_R, kFastCAP = CQ_FAST_CAP;
+// Reads per wave sub-tile of the fast kernel: eight, or four when eight reads' rows and hash words take so much
+// LDS that fewer workgroups stay resident (long reads) -- chosen per launch, see launch_classify.
+constexpr int kFastCAP = CQ_FAST_CAP;
 constexpr int kSlowR = 1, kSlowCAP = 1024;
-constexpr uint64_t kMaxSubPerWave = 32767 / (kWaves * kFastR);   // 1023 sub-tiles: <= 32736 reads per workgroup and launch
+constexpr uint64_t kMaxReadsPerGroup = 32767;   // per workgroup and launch: the LDS histogram's 15-bit halves (see launch_fast)
 
 static size_t smem_bytes(int R, int CAP, const QueryArgs &a, bool hist)
 {
@@ -812,6 +811,65 @@ hipError_t launch_accumulate(uint64_t *dst64, const uint64_t *src64, uint64_t n6
     return hipGetLastError();
 }
 
+namespace {
+
+template <int R>
+hipError_t fast_resident(const QueryArgs &a, bool hist, int &n)
+{
+    // LDS above the 64 KiB default needs an explicit opt-in (large G)
+    hipError_t e = hipFuncSetAttribute((const void *)classify_kernel<R, kFastCAP, false>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    const size_t sm = smem_bytes(R, kFastCAP, a, hist);
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)classify_kernel<R, kFastCAP, false>, kBlock, sm);
+    // The 160 KB are handed out in 1280-byte granules (measured: 5 x 32292 B = 161460 B fit by arithmetic and by the
+    // occupancy query, yet only four such workgroups were resident; 5 x 31524 B were): a sub-tile or a histogram
+    // that just fits can still cost a workgroup, so count in granules.
+    const int by_granules = (int)((160u * 1024u) / ((sm + 1279u) / 1280u * 1280u));
+    if (n > by_granules) n = by_granules;
+    if (n > CQ_MAX_BLOCKS_PER_CU) n = CQ_MAX_BLOCKS_PER_CU;
+    return e;
+}
+
+// The fast kernel: persistent waves, each walking its own sub-tiles of R reads.
+template <int R>
+hipError_t launch_fast(const DevIndex &ix, QueryArgs &a, int n_cus, int per_cu, hipStream_t stream)
+{
+    const size_t sm = smem_bytes(R, kFastCAP, a, a.use_lds_hist);
+    if (const char *v = getenv("CAMMIQ_BLOCKS_PER_CU")) per_cu = atoi(v);   // tuning knob
+    if (per_cu < 1) per_cu = 1;
+    const uint64_t grid_full = (uint64_t)n_cus * per_cu;
+    // The LDS histogram keeps cnt_u and cnt_d of a genome in the two halves of one word; one read adds at most
+    // 1 to a genome's cnt_u and at most 2 to its cnt_d (a pair (g, g)), so a workgroup must not classify more than
+    // 32767 reads per launch: a wave takes at most max_sub sub-tiles, longer inputs are cut into several
+    // launches (configs[2]'s 50 M reads per launch still fit one: 1536 workgroups x 32736 reads).
+    uint64_t max_sub = kMaxReadsPerGroup / (kWaves * R);
+    if (const char *v = getenv("CAMMIQ_MAX_SUB_PER_WAVE")) max_sub = (uint64_t)atoi(v) >= 1 && (uint64_t)atoi(v) < max_sub ? (uint64_t)atoi(v) : max_sub;   // test knob
+    const uint64_t chunk = a.use_lds_hist ? grid_full * kWaves * max_sub * R : a.n_reads;
+    const uint32_t *packed0 = a.packed;
+    const uint8_t *lens0 = a.lens;
+    const uint64_t n_total = a.n_reads;
+    hipError_t e = hipSuccess;
+    for (uint64_t c0 = 0; c0 < n_total; c0 += chunk) {
+        a.read0 = c0;
+        a.n_reads = n_total - c0 < chunk ? n_total - c0 : chunk;
+        a.packed = packed0 + c0 * a.stride_words;
+        a.lens = lens0 + c0;
+        const uint64_t n_sub = (a.n_reads + R - 1) / R;
+        uint64_t grid = grid_full;
+        const uint64_t need = (n_sub + kWaves - 1) / kWaves;
+        if (grid > need) grid = need;
+        if (grid == 0) grid = 1;
+        hipLaunchKernelGGL((classify_kernel<R, kFastCAP, false>), dim3((unsigned)grid), dim3(kBlock), sm, stream, ix, a);
+        e = hipGetLastError();
+        if (e != hipSuccess) break;
+    }
+    a.read0 = 0; a.n_reads = n_total; a.packed = packed0; a.lens = lens0;
+    return e;
+}
+
+}  // namespace
+
 hipError_t launch_classify(const DevIndex &ix, QueryArgs a, int n_cus, hipStream_t stream,
                            hipEvent_t ev_start, hipEvent_t ev_mid, hipEvent_t ev_stop)
 {
@@ -821,65 +879,27 @@ hipError_t launch_classify(const DevIndex &ix, QueryArgs a, int n_cus, hipStream
     a.magic_p = magic_of(a.pmax);
     a.magic_s = magic_of(a.stride_words);
     a.magic_pp = magic_of((a.pmax + kPrePos - 1u) / kPrePos);
-    // Per-genome counters: an LDS histogram per workgroup when it costs no resident workgroup (six per CU is what
-    // the registers allow), global 64-bit atomics otherwise -- measured: the atomics cost 4 %, a lost workgroup 8 %.
-    a.use_lds_hist = lds_hist_fits(a.n_genomes) ? 1 : 0;
-    if (a.use_lds_hist && !getenv("CAMMIQ_LDS_HIST_MAX")) {
-        auto resident = [&](bool hist) {
-            const size_t per_cu = (160u * 1024u) / smem_bytes(kFastR, kFastCAP, a, hist);
-            return per_cu < (size_t)CQ_MAX_BLOCKS_PER_CU ? per_cu : (size_t)CQ_MAX_BLOCKS_PER_CU;
-        };
-        if (resident(true) < resident(false)) a.use_lds_hist = 0;
-    }
-    hipError_t e;
-    // LDS above the 64 KiB default needs an explicit opt-in (large G)
-    e = hipFuncSetAttribute((const void *)classify_kernel<kFastR, kFastCAP, false>,
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipError_t e = hipFuncSetAttribute((const void *)classify_kernel<kSlowR, kSlowCAP, true>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute((const void *)classify_kernel<kSlowR, kSlowCAP, true>,
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    // Two choices per launch, both by what stays resident (six workgroups per CU is what the registers allow):
+    //  * reads per sub-tile: eight, unless eight leave three workgroups or fewer and four keep more (rows and hash
+    //    words of long reads);
+    //  * per-genome counters: an LDS histogram per workgroup when it costs no resident workgroup, global 64-bit
+    //    atomics otherwise -- measured: the atomics cost 4 %, a lost workgroup 8 %.
+    const bool hist_ok = lds_hist_fits(a.n_genomes), hist_forced = getenv("CAMMIQ_LDS_HIST_MAX") != nullptr;
+    int r8 = 0, r4 = 0, r8h = 0, r4h = 0;
+    if ((e = fast_resident<8>(a, false, r8)) != hipSuccess || (e = fast_resident<4>(a, false, r4)) != hipSuccess) return e;
+    if (hist_ok && ((e = fast_resident<8>(a, true, r8h)) != hipSuccess || (e = fast_resident<4>(a, true, r4h)) != hipSuccess)) return e;
+    int R = (r8 <= 3 && r4 > r8) ? 4 : 8;   // measured: four reads per sub-tile cost 14 % at equal residency and 8 % at 6 against 5 workgroups (150 bp), and win 13 % at 6 against 3 (250 bp)
+    if (const char *v = getenv("CAMMIQ_FAST_R")) R = atoi(v) == 4 ? 4 : 8;   // tuning knob
+    const int plain = R == 8 ? r8 : r4, with = R == 8 ? r8h : r4h;
+    a.use_lds_hist = hist_ok && (hist_forced || with >= plain) ? 1 : 0;
+    const int per_cu = a.use_lds_hist ? with : plain;
+    if (ev_start) { e = hipEventRecord(ev_start, stream); if (e != hipSuccess) return e; }
+    e = R == 8 ? launch_fast<8>(ix, a, n_cus, per_cu, stream) : launch_fast<4>(ix, a, n_cus, per_cu, stream);
     if (e != hipSuccess) return e;
-    // fast kernel: persistent waves, each walking its own sub-tiles
-    uint64_t grid_full = 1;
-    {
-        const size_t sm = smem_bytes(kFastR, kFastCAP, a, a.use_lds_hist);
-        // persistent grid = what is resident (registers and LDS decide), at most 6 workgroups per CU
-        int per_cu = 0;
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)classify_kernel<kFastR, kFastCAP, false>,
-                                                         kBlock, sm);
-        if (e != hipSuccess) return e;
-        if (per_cu > CQ_MAX_BLOCKS_PER_CU) per_cu = CQ_MAX_BLOCKS_PER_CU;
-        if (const char *v = getenv("CAMMIQ_BLOCKS_PER_CU")) per_cu = atoi(v);   // tuning knob
-        if (per_cu < 1) per_cu = 1;
-        grid_full = (uint64_t)n_cus * per_cu;
-        // The LDS histogram keeps cnt_u and cnt_d of a genome in the two halves of one word; one read adds at most
-        // 1 to a genome's cnt_u and at most 2 to its cnt_d (a pair (g, g)), so a workgroup must not classify more than
-        // 32767 reads per launch: a wave takes at most kMaxSubPerWave sub-tiles, longer inputs are cut into several
-        // launches (configs[2]'s 50 M reads per launch still fit one: 1536 workgroups x 32736 reads).
-        uint64_t max_sub = kMaxSubPerWave;
-        if (const char *v = getenv("CAMMIQ_MAX_SUB_PER_WAVE")) max_sub = (uint64_t)atoi(v) >= 1 && (uint64_t)atoi(v) < max_sub ? (uint64_t)atoi(v) : max_sub;   // test knob
-        const uint64_t chunk = a.use_lds_hist ? grid_full * kWaves * max_sub * kFastR : a.n_reads;
-        const uint32_t *packed0 = a.packed;
-        const uint8_t *lens0 = a.lens;
-        const uint64_t n_total = a.n_reads;
-        if (ev_start) { e = hipEventRecord(ev_start, stream); if (e != hipSuccess) return e; }
-        for (uint64_t c0 = 0; c0 < n_total; c0 += chunk) {
-            a.read0 = c0;
-            a.n_reads = n_total - c0 < chunk ? n_total - c0 : chunk;
-            a.packed = packed0 + c0 * a.stride_words;
-            a.lens = lens0 + c0;
-            const uint64_t n_sub = (a.n_reads + kFastR - 1) / kFastR;
-            uint64_t grid = grid_full;
-            const uint64_t need = (n_sub + kWaves - 1) / kWaves;
-            if (grid > need) grid = need;
-            if (grid == 0) grid = 1;
-            hipLaunchKernelGGL((classify_kernel<kFastR, kFastCAP, false>), dim3((unsigned)grid), dim3(kBlock), sm, stream, ix, a);
-            e = hipGetLastError();
-            if (e != hipSuccess) return e;
-        }
-        a.read0 = 0; a.n_reads = n_total; a.packed = packed0; a.lens = lens0;
-        if (ev_mid) { e = hipEventRecord(ev_mid, stream); if (e != hipSuccess) return e; }
-    }
+    if (ev_mid) { e = hipEventRecord(ev_mid, stream); if (e != hipSuccess) return e; }
     // exact slow path for reads with more than kFastCAP hits (usually none: the kernel reads the count from
     // device memory and exits at once).  One read per wave; enough workgroups that none takes more than 32767.
     {

@@ -22,7 +22,7 @@ from util import assert_same, build_index
 pytestmark = pytest.mark.gpu
 
 _KNOBS = ("CAMMIQ_MAX_SUB_PER_WAVE", "CAMMIQ_LDS_HIST_MAX", "CAMMIQ_KEYS_PER_BUCKET", "CAMMIQ_BLOCKS_PER_CU",
-          "CAMMIQ_PAIR_SLOTS")
+          "CAMMIQ_PAIR_SLOTS", "CAMMIQ_FAST_R")
 
 
 def _draw(seed):
@@ -54,6 +54,8 @@ def _draw(seed):
         w["env"]["CAMMIQ_BLOCKS_PER_CU"] = r.choice(["1", "2", "4"])
     if r.random() < 0.3:
         w["env"]["CAMMIQ_PAIR_SLOTS"] = r.choice(["16", "64"])               # SC mode has to grow the pair table
+    if r.random() < 0.4:
+        w["env"]["CAMMIQ_FAST_R"] = r.choice(["4", "8"])                     # reads per wave sub-tile, either way at any length
     return w
 
 
@@ -150,6 +152,8 @@ def _draw_generator(seed):
         w["env"]["CAMMIQ_KEYS_PER_BUCKET"] = r.choice(["0.5", "2.0", "3.2", "3.9"])
     if r.random() < 0.3:
         w["env"]["CAMMIQ_PAIR_SLOTS"] = "64"
+    if r.random() < 0.4:
+        w["env"]["CAMMIQ_FAST_R"] = r.choice(["4", "8"])
     return w
 
 

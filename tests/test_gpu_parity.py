@@ -334,3 +334,30 @@ def test_long_inputs_are_cut_into_several_launches(tmp_path, monkeypatch):
     monkeypatch.setenv("CAMMIQ_BLOCKS_PER_CU", "1")                         # 256 x 4 waves x 1 sub-tile x 8 = 8192 reads per launch
     got = cq.Index(pu, pd, device=0).query(b, o, len(gen))
     assert_same(got, ref, "several launches")
+    monkeypatch.setenv("CAMMIQ_FAST_R", "4")                                # four reads per sub-tile: 4096 reads per launch
+    assert_same(cq.Index(pu, pd, device=0).query(b, o, len(gen)), ref, "several launches, R = 4")
+
+
+@pytest.mark.parametrize("rl", [100, 255])
+def test_reads_per_sub_tile_do_not_change_the_result(tmp_path, monkeypatch, rl):
+    """The launcher gives a wave eight reads per sub-tile, or four when eight reads' rows and hash words would
+    leave three workgroups or fewer resident (long reads).  Both, and the automatic choice, against the oracle,
+    with the per-genome counters in LDS and as global atomics."""
+    gen = synth.clade_genomes(52, 3, 3, 3000, 0.03)
+    u, d = synth.select_markers(gen, 26, 40, keep_every=2, seed=5)
+    pu, pd = build_index(tmp_path, u, d, 26)
+    reads = synth.simulate_reads(gen, 20011, rl, 0.01, 8, frac_random=0.1)   # ragged last sub-tile for 4 and for 8
+    b, o = synth.concat_reads(reads)
+    oi = oracle_lib.OracleIndex(pu, pd)
+    for mode in (cq.MODE_P, cq.MODE_SC):
+        ref = oi.query(b, o, len(gen), mode=mode, nthreads=8)
+        for R in ("8", "4", None):
+            for hist in ("1000000", "0"):
+                monkeypatch.setenv("CAMMIQ_LDS_HIST_MAX", hist)
+                if R:
+                    monkeypatch.setenv("CAMMIQ_FAST_R", R)
+                else:
+                    monkeypatch.delenv("CAMMIQ_FAST_R", raising=False)
+                got = cq.Index(pu, pd, device=0).query(b, o, len(gen), mode=mode)
+                assert_same(got, ref, f"rl={rl} R={R} hist={hist} mode={mode}", rcount=(mode == cq.MODE_P))
+                assert got["pairs"] == ref["pairs"]
