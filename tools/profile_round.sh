@@ -35,7 +35,7 @@ for c in ("FETCH_SIZE","WRITE_SIZE"):
 # bytes.  The only such stream here is the packed rows (16 B per lane, read once): add the missing half.  The
 # rest of the kernel's reads are random 64-byte bucket / 16-byte node reads, calibrated at x1.0 in round 1
 # (profiles/r01_v1_traffic.json: 1.5e9 known bucket reads x 64 B).
-rows=cfg["reads_per_gpu"]*32+cfg["reads_per_gpu"]
+rows=cfg["reads_per_gpu"]*((cfg["read_len"]+15)//16*4+1)   # rows of ceil(len/16) words + one length byte per read
 res["row_stream_bytes"]=rows
 res["hbm_bytes_per_launch"]=(res["FETCH_SIZE_KB_per_launch"]+res["WRITE_SIZE_KB_per_launch"])*1024+0.5*rows
 res["workload_key"]=cfg["workload_key"]; res["table_GB"]=cfg["table_GB"]
