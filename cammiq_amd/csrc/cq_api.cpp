@@ -663,6 +663,8 @@ int classify_range(cq_index *ix, int mode, const Feed &f, uint64_t lo, uint64_t 
     const bool ascii = f.packed == nullptr;
     int rc = CQ_OK;
     uint64_t c = 0;
+    // inside the loop a failed HIP call ends the loop instead of returning: copies from the caller's memory may be in flight
+#define CQ_HIPB(call) if (hipError_t e_ = (call)) { rc = fail(CQ_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); break; } else (void)0
     for (uint64_t c0 = lo; c0 < hi && rc == CQ_OK; c0 += kChunk, c++) {
         cq_index::Slot &sl = ix->slot[c % 3];
         const uint64_t n = std::min(kChunk, hi - c0);
@@ -676,7 +678,7 @@ int classify_range(cq_index *ix, int mode, const Feed &f, uint64_t lo, uint64_t 
             }
             sw = cq_pack_stride_words((uint32_t)max_len);
         }
-        if (sl.done) CQ_HIP(hipEventSynchronize(sl.done));      // the kernel that last used this slot
+        if (sl.done) { CQ_HIPB(hipEventSynchronize(sl.done)); }   // the kernel that last used this slot
         rc = slot_reserve(sl, n, sw, ascii);
         if (rc != CQ_OK) break;
         const uint32_t *src_rows = nullptr;
@@ -691,12 +693,12 @@ int classify_range(cq_index *ix, int mode, const Feed &f, uint64_t lo, uint64_t 
             src_rows = f.packed + (size_t)c0 * sw;
             src_lens = f.lens + c0;
         }
-        CQ_HIP(hipMemcpyAsync(sl.d_packed, src_rows, (size_t)n * sw * 4, hipMemcpyHostToDevice, ix->s_copy));
-        CQ_HIP(hipEventRecord(sl.copied, ix->s_copy));
+        CQ_HIPB(hipMemcpyAsync(sl.d_packed, src_rows, (size_t)n * sw * 4, hipMemcpyHostToDevice, ix->s_copy));
+        CQ_HIPB(hipEventRecord(sl.copied, ix->s_copy));
         // the small copy of the lengths goes down its own queue: behind the rows it would put a bubble between
         // every two large transfers
-        CQ_HIP(hipMemcpyAsync(sl.d_lens, src_lens, n, hipMemcpyHostToDevice, ix->s_copy2));
-        CQ_HIP(hipEventRecord(sl.copied_lens, ix->s_copy2));
+        CQ_HIPB(hipMemcpyAsync(sl.d_lens, src_lens, n, hipMemcpyHostToDevice, ix->s_copy2));
+        CQ_HIPB(hipEventRecord(sl.copied_lens, ix->s_copy2));
         if (!ascii) {
             // The lane grid is sized by the longest read: take it from the lengths themselves (a max_len that is too
             // small would silently drop windows) and refuse lengths the rows cannot hold.  Done while the copies are in
@@ -706,13 +708,14 @@ int classify_range(cq_index *ix, int mode, const Feed &f, uint64_t lo, uint64_t 
             if (longest > sw * 16u) { rc = fail(CQ_ERR_ARG, "cq_query_packed: a length exceeds 16 x stride_words bases"); break; }
             max_len = std::max<uint64_t>(max_len, longest);
         }
-        CQ_HIP(hipStreamWaitEvent(ix->s_comp, sl.copied, 0));
-        CQ_HIP(hipStreamWaitEvent(ix->s_comp, sl.copied_lens, 0));
+        CQ_HIPB(hipStreamWaitEvent(ix->s_comp, sl.copied, 0));
+        CQ_HIPB(hipStreamWaitEvent(ix->s_comp, sl.copied_lens, 0));
         rc = cq_query_device(ix, mode, sl.d_packed, sl.d_lens, n, sw, (uint32_t)max_len, n_genomes, ix->d_ctr, d_rc,
                              ix->s_comp);
         if (rc != CQ_OK) break;
-        CQ_HIP(hipEventRecord(sl.done, ix->s_comp));
+        CQ_HIPB(hipEventRecord(sl.done, ix->s_comp));
     }
+#undef CQ_HIPB
     if (hipStreamSynchronize(ix->s_comp) != hipSuccess && rc == CQ_OK) rc = fail(CQ_ERR_HIP, "classify kernel failed");
     if (rc != CQ_OK) {   // an error may have left copies from the caller's memory in flight with no kernel behind them
         (void)hipStreamSynchronize(ix->s_copy);
