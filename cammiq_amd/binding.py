@@ -67,6 +67,14 @@ SIGNATURES = {
     "cq_last_kernel_times": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "cq_query_packed": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32,
                                   C.c_uint32, C.c_uint32, C.POINTER(_Counts)]),
+    "cq_pack_stride_bytes": (C.c_uint32, [C.c_uint32]),
+    "cq_pack_reads_tight": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p,
+                                      C.c_void_p, C.POINTER(C.c_uint64)]),
+    "cq_pack_read_tight": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
+    "cq_query_packed_tight": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32,
+                                        C.c_uint32, C.c_uint32, C.POINTER(_Counts)]),
+    "cq_multi_query_packed_tight": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32,
+                                              C.c_uint32, C.c_uint32, C.POINTER(_Counts)]),
     "cq_host_alloc": (C.c_int, [C.POINTER(C.c_void_p), C.c_size_t]),
     "cq_host_free": (None, [C.c_void_p]),
     "cq_pairs_reserve": (C.c_int, [C.c_void_p, C.c_uint64]),
@@ -134,6 +142,25 @@ def pack_reads(bases: np.ndarray, offsets: np.ndarray, hash_len: int, sw: int | 
     lens = np.zeros(n, np.uint8)
     sk = C.c_uint64(0)
     _check(lib().cq_pack_reads(_p(bases), _p(offsets), n, hash_len, sw, _p(packed), _p(lens), C.byref(sk)))
+    return packed, lens, int(sk.value)
+
+
+def stride_bytes(max_len: int) -> int:
+    return int(lib().cq_pack_stride_bytes(int(max_len)))
+
+
+def pack_reads_tight(bases: np.ndarray, offsets: np.ndarray, hash_len: int, sb: int | None = None, out=None):
+    """ASCII -> (tight rows uint8 [n, sb], lens uint8 [n], n_skipped): 25 bytes per 100-bp read for the host link."""
+    bases = np.ascontiguousarray(bases, np.uint8)
+    offsets = np.ascontiguousarray(offsets, np.uint64)
+    n = len(offsets) - 1
+    if sb is None:
+        ml = int(np.diff(offsets.astype(np.int64)).clip(max=255).max()) if n else 0
+        sb = stride_bytes(ml)
+    packed, lens = out if out is not None else (np.zeros((n, sb), np.uint8), np.zeros(n, np.uint8))
+    assert packed.shape == (n, sb) and packed.flags.c_contiguous and lens.shape == (n,)
+    sk = C.c_uint64(0)
+    _check(lib().cq_pack_reads_tight(_p(bases), _p(offsets), n, hash_len, sb, _p(packed), _p(lens), C.byref(sk)))
     return packed, lens, int(sk.value)
 
 
@@ -240,6 +267,15 @@ class Index:
                                      n_genomes, C.byref(o.c)))
         return o.result()
 
+    def query_packed_tight(self, packed: np.ndarray, lens: np.ndarray, max_len: int, n_genomes: int,
+                           mode: int = MODE_P, pair_cap: int = 1 << 16, out: "_CountsOut | None" = None):
+        """cq_query_packed_tight: rows at a byte stride (pack_reads_tight) -> H2D, widened on the device, classified."""
+        assert packed.dtype == np.uint8 and packed.flags.c_contiguous and lens.dtype == np.uint8
+        o = out or _CountsOut(n_genomes, self.n_leaves, pair_cap)
+        _check(lib().cq_query_packed_tight(self._h, mode, _p(packed), _p(lens), len(lens), packed.shape[1], max_len,
+                                           n_genomes, C.byref(o.c)))
+        return o.result()
+
     def counts_out(self, n_genomes: int, pair_cap: int = 1 << 16, pinned: bool = True) -> "_CountsOut":
         """Reusable output arrays (rcount in page-locked memory when pinned)."""
         return _CountsOut(n_genomes, self.n_leaves, pair_cap, pinned=pinned)
@@ -322,6 +358,13 @@ class Multi:
         o = out or _CountsOut(n_genomes, self.n_leaves, pair_cap)
         _check(lib().cq_multi_query_packed(self._h, mode, _p(packed), _p(lens), len(lens), packed.shape[1], max_len,
                                            n_genomes, C.byref(o.c)))
+        return o.result()
+
+    def query_packed_tight(self, packed, lens, max_len, n_genomes, mode=MODE_P, pair_cap=1 << 16, out=None):
+        assert packed.dtype == np.uint8 and packed.flags.c_contiguous and lens.dtype == np.uint8
+        o = out or _CountsOut(n_genomes, self.n_leaves, pair_cap)
+        _check(lib().cq_multi_query_packed_tight(self._h, mode, _p(packed), _p(lens), len(lens), packed.shape[1], max_len,
+                                                 n_genomes, C.byref(o.c)))
         return o.result()
 
     def close(self):

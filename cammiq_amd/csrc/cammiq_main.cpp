@@ -101,20 +101,21 @@ std::vector<Genome> load_map(const std::string &fn)
 // memory-mapped and split at line boundaries across threads.  Two passes: (1) every chunk counts
 // its lines and, for each of the four possible positions of its first line in a FASTQ record, the
 // sequence lines, their bytes and their longest length; a prefix sum over the chunks then fixes
-// everything; (2) every chunk packs its sequence lines straight into 2-bit rows (cq_pack_read),
-// which is what cq_query_packed takes -- the ASCII reads are never copied (--fastq_stats keeps an
+// everything; (2) every chunk packs its sequence lines straight into tight 2-bit rows (cq_pack_read_tight:
+// 25 bytes per 100-bp read, what crosses the host link), which is what cq_query_packed_tight takes -- the
+// ASCII reads are never copied (--fastq_stats keeps an
 // ASCII pass 2 for its digest).  The output buffers are not initialised first (their pages are
 // first touched by the copying threads).
 struct Reads {
     std::unique_ptr<uint8_t[]> bases;   // ASCII (--fastq_stats only)
     std::unique_ptr<uint64_t[]> offs;   // n_reads + 1
-    std::unique_ptr<uint32_t[]> packed; // 2-bit rows, stride sw words (queries: the ASCII reads are never materialised)
+    std::unique_ptr<uint8_t[]> packed;  // tight 2-bit rows, stride sb bytes (queries: the ASCII reads are never materialised)
     std::unique_ptr<uint8_t[]> lens;
-    uint32_t sw = 1, max_len = 0;
+    uint32_t sb = 1, max_len = 0;
     size_t n_reads = 0, n_bases = 0;
 };
 
-// pack = true: pass 2 writes 2-bit rows (cq_pack_read) straight from the mapped file instead of an ASCII copy.
+// pack = true: pass 2 writes 2-bit rows (cq_pack_read_tight) straight from the mapped file instead of an ASCII copy.
 void read_fastq(const std::string &fn, size_t min_l, Reads &out, bool pack = false)
 {
     const bool timing = getenv("CAMMIQ_LOAD_TIMING") != nullptr;
@@ -176,10 +177,10 @@ void read_fastq(const std::string &fn, size_t min_l, Reads &out, bool pack = fal
     }
     out.n_reads = r0[T];
     out.n_bases = b0[T];
-    out.sw = cq_pack_stride_words(out.max_len);
-    const uint32_t sw = out.sw;
+    out.sb = cq_pack_stride_bytes(out.max_len);
+    const uint32_t sb = out.sb;
     if (pack) {
-        out.packed.reset(new uint32_t[out.n_reads * sw + 1]);
+        out.packed.reset(new uint8_t[out.n_reads * sb + 1]);
         out.lens.reset(new uint8_t[out.n_reads + 1]);
     } else {
         out.bases.reset(new uint8_t[out.n_bases ? out.n_bases : 1]);
@@ -190,7 +191,7 @@ void read_fastq(const std::string &fn, size_t min_l, Reads &out, bool pack = fal
     const char alphabet[4] = {'A', 'C', 'G', 'T'};
     uint8_t *const bases = out.bases.get();
     uint64_t *const offs = out.offs.get();
-    uint32_t *const packed = out.packed.get();
+    uint8_t *const packed = out.packed.get();
     uint8_t *const lens = out.lens.get();
     for_chunks([&](unsigned c) {
         uint64_t r = r0[c], b = b0[c], li = line0[c];
@@ -212,8 +213,8 @@ void read_fastq(const std::string &fn, size_t min_l, Reads &out, bool pack = fal
                             src = tmp;
                         }
                         // reads longer than 255 bases are outside the parity domain (the reference keeps lengths in a uint8_t)
-                        if (len > 255) { memset(packed + r * sw, 0, (size_t)sw * 4); lens[r] = 0; }
-                        else cq_pack_read(src, (uint32_t)len, 1, sw, packed + r * sw, lens + r);
+                        if (len > 255) { memset(packed + r * sb, 0, sb); lens[r] = 0; }
+                        else cq_pack_read_tight(src, (uint32_t)len, 1, sb, packed + r * sb, lens + r);
                         r++;
                     } else {
                         offs[r++] = b;
@@ -447,8 +448,8 @@ int main(int argc, char **argv)
             c.cnt_u = cu.data(); c.cnt_d = cd.data();
             c.rcount_u = ru.empty() ? nullptr : ru.data(); c.rcount_d = rd.empty() ? nullptr : rd.data();
             c.pair_a = pa.data(); c.pair_b = pb.data(); c.pair_cnt = pc.data(); c.pair_cap = pc.size();
-            rc = mx ? cq_multi_query_packed(mx, qmode, fq.packed.get(), fq.lens.get(), fq.n_reads, fq.sw, fq.max_len, G, &c)
-                    : cq_query_packed(ix, qmode, fq.packed.get(), fq.lens.get(), fq.n_reads, fq.sw, fq.max_len, G, &c);
+            rc = mx ? cq_multi_query_packed_tight(mx, qmode, fq.packed.get(), fq.lens.get(), fq.n_reads, fq.sb, fq.max_len, G, &c)
+                    : cq_query_packed_tight(ix, qmode, fq.packed.get(), fq.lens.get(), fq.n_reads, fq.sb, fq.max_len, G, &c);
             if (rc == CQ_ERR_LIMIT && c.n_pairs > pc.size()) {   // read_cnts_b has more entries than the arrays: grow, ask again
                 pa.resize(c.n_pairs); pb.resize(c.n_pairs); pc.resize(c.n_pairs);
                 if (!mx) {   // the single-GPU library kept the pairs: fetch them, no second classify

@@ -55,7 +55,11 @@ int fail(int code, const std::string &msg)
     } while (0)
 
 constexpr uint32_t kPairCapDefault = 1u << 20;   // slots of the SC-mode pair map (grown on demand)
-constexpr uint64_t kChunk = 1ull << 21;          // reads per pipelined chunk of the host-fed paths
+const uint64_t kChunk = [] {                     // reads per pipelined chunk of the host-fed paths (CAMMIQ_CHUNK_READS: tuning knob)
+    const char *v = getenv("CAMMIQ_CHUNK_READS");
+    const unsigned long long n = v ? strtoull(v, nullptr, 10) : 0;
+    return n >= 1024 && n <= (1ull << 28) ? (uint64_t)n : (1ull << 21);
+}();
 constexpr size_t kBounce = 16u << 20;            // pinned bounce buffer for D2H into pageable arrays
 
 // What decode + layout leave on the host.  One copy serves every handle of a cq_multi (the
@@ -92,10 +96,12 @@ struct cq_index {
     struct Slot {
         uint32_t *h_packed = nullptr, *d_packed = nullptr;   // pinned host / device rows
         uint8_t *h_lens = nullptr, *d_lens = nullptr;
-        size_t cap_words_h = 0, cap_reads_h = 0, cap_words_d = 0, cap_reads_d = 0;
-        hipEvent_t copied = nullptr, copied_lens = nullptr, done = nullptr;
+        uint8_t *d_tight = nullptr;                          // tight rows as they arrive (cq_query_packed_tight), widened into d_packed
+        size_t cap_words_h = 0, cap_reads_h = 0, cap_words_d = 0, cap_reads_d = 0, cap_tight = 0;
+        hipEvent_t copied = nullptr, copied_lens = nullptr, widened = nullptr, done = nullptr;
     } slot[3];   // three: the host may enqueue the copy of chunk c+1 while kernel c-1 is still running
     hipStream_t s_copy = nullptr, s_copy2 = nullptr, s_comp = nullptr;   // rows | lengths (their own DMA queue) | kernels
+    hipStream_t s_widen = nullptr;   // tight rows -> word rows, beside the classify kernel of the chunk before (it leaves wave slots free)
     uint64_t *d_ctr = nullptr; size_t ctr_cap = 0;
     uint32_t *d_rc = nullptr; size_t rc_cap = 0;
     void *h_bounce[2] = {nullptr, nullptr};
@@ -148,14 +154,17 @@ void release_device(cq_index *ix)
         if (sl.h_lens) (void)hipHostFree(sl.h_lens);
         if (sl.d_packed) (void)hipFree(sl.d_packed);
         if (sl.d_lens) (void)hipFree(sl.d_lens);
+        if (sl.d_tight) (void)hipFree(sl.d_tight);
         if (sl.copied) (void)hipEventDestroy(sl.copied);
         if (sl.copied_lens) (void)hipEventDestroy(sl.copied_lens);
+        if (sl.widened) (void)hipEventDestroy(sl.widened);
         if (sl.done) (void)hipEventDestroy(sl.done);
     }
     for (void *b : ix->h_bounce) if (b) (void)hipHostFree(b);
     if (ix->s_copy) (void)hipStreamDestroy(ix->s_copy);
     if (ix->s_copy2) (void)hipStreamDestroy(ix->s_copy2);
     if (ix->s_comp) (void)hipStreamDestroy(ix->s_comp);
+    if (ix->s_widen) (void)hipStreamDestroy(ix->s_widen);
     if (ix->d_ctr) (void)hipFree(ix->d_ctr);
     if (ix->d_rc) (void)hipFree(ix->d_rc);
 }
@@ -546,6 +555,15 @@ int cq_pairs_fetch(cq_index *ix, uint32_t *pair_a, uint32_t *pair_b, uint64_t *p
 
 namespace {
 
+// The widening kernel's queue: high priority, so that it gets a hardware queue of its own and runs in the wave
+// slots the classify kernel of the chunk before leaves free, instead of queueing up behind it.
+hipError_t make_widen_stream(cq_index *ix)
+{
+    int lo = 0, hi = 0;
+    if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { lo = hi = 0; (void)hipGetLastError(); }
+    return hipStreamCreateWithPriority(&ix->s_widen, hipStreamNonBlocking, hi);
+}
+
 // Grow one staging slot: device rows for n reads of sw words, and (host_too) the pinned host side.
 int slot_reserve(cq_index::Slot &sl, uint64_t n, uint32_t sw, bool host_too)
 {
@@ -576,6 +594,7 @@ int slot_reserve(cq_index::Slot &sl, uint64_t n, uint32_t sw, bool host_too)
     }
     if (!sl.copied) CQ_HIP(hipEventCreateWithFlags(&sl.copied, hipEventDisableTiming));
     if (!sl.copied_lens) CQ_HIP(hipEventCreateWithFlags(&sl.copied_lens, hipEventDisableTiming));
+    if (!sl.widened) CQ_HIP(hipEventCreateWithFlags(&sl.widened, hipEventDisableTiming));
     if (!sl.done) CQ_HIP(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
     return CQ_OK;
 }
@@ -591,7 +610,11 @@ void warm_workspace(cq_index *ix)
     if (!ix->s_copy) (void)hipStreamCreateWithFlags(&ix->s_copy, hipStreamNonBlocking);
     if (!ix->s_copy2) (void)hipStreamCreateWithFlags(&ix->s_copy2, hipStreamNonBlocking);
     if (!ix->s_comp) (void)hipStreamCreateWithFlags(&ix->s_comp, hipStreamNonBlocking);
-    for (auto &sl : ix->slot) (void)slot_reserve(sl, kChunk, 8, false);
+    if (!ix->s_widen) (void)make_widen_stream(ix);
+    for (auto &sl : ix->slot) {
+        (void)slot_reserve(sl, kChunk, 8, false);
+        if (!sl.d_tight && hipMalloc((void **)&sl.d_tight, kChunk * 32) == hipSuccess) sl.cap_tight = kChunk * 32;   // tight rows of up to 128 bases
+    }
     for (int b = 0; b < 2; b++) {
         if (!ix->h_bounce[b] && hipHostMalloc(&ix->h_bounce[b], kBounce, hipHostMallocDefault) != hipSuccess) ix->h_bounce[b] = nullptr;
         if (!ix->ev_bounce[b]) (void)hipEventCreateWithFlags(&ix->ev_bounce[b], hipEventDisableTiming);
@@ -609,8 +632,9 @@ struct Feed {
     const uint8_t *bases = nullptr;
     const uint64_t *offsets = nullptr;
     const uint32_t *packed = nullptr;
+    const uint8_t *tight = nullptr;   // rows at a byte stride of sb (cq_pack_reads_tight); sw = ceil(sb / 4)
     const uint8_t *lens = nullptr;
-    uint32_t sw = 0, max_len = 0;
+    uint32_t sw = 0, sb = 0, max_len = 0;
 };
 
 int query_checks(const cq_index *ix, int mode, uint32_t n_genomes, const cq_counts *out, const char *who)
@@ -640,6 +664,7 @@ int classify_range(cq_index *ix, int mode, const Feed &f, uint64_t lo, uint64_t 
     if (!ix->s_copy) CQ_HIP(hipStreamCreateWithFlags(&ix->s_copy, hipStreamNonBlocking));
     if (!ix->s_copy2) CQ_HIP(hipStreamCreateWithFlags(&ix->s_copy2, hipStreamNonBlocking));
     if (!ix->s_comp) CQ_HIP(hipStreamCreateWithFlags(&ix->s_comp, hipStreamNonBlocking));
+    if (!ix->s_widen) CQ_HIP(make_widen_stream(ix));
     const uint64_t cw = cq_counter_words(n_genomes);
     const uint64_t nl = img.n_leaves[0] + img.n_leaves[1];
     if (ix->ctr_cap < cw) {
@@ -660,7 +685,7 @@ int classify_range(cq_index *ix, int mode, const Feed &f, uint64_t lo, uint64_t 
         d_rc = ix->d_rc;
         CQ_HIP(hipMemsetAsync(d_rc, 0, nl * 4, ix->s_comp));
     }
-    const bool ascii = f.packed == nullptr;
+    const bool ascii = f.packed == nullptr && f.tight == nullptr;
     int rc = CQ_OK;
     uint64_t c = 0;
     // inside the loop a failed HIP call ends the loop instead of returning: copies from the caller's memory may be in flight
@@ -690,10 +715,19 @@ int classify_range(cq_index *ix, int mode, const Feed &f, uint64_t lo, uint64_t 
             src_rows = sl.h_packed;
             src_lens = sl.h_lens;
         } else {
-            src_rows = f.packed + (size_t)c0 * sw;
+            src_rows = f.tight ? nullptr : f.packed + (size_t)c0 * sw;
             src_lens = f.lens + c0;
         }
-        CQ_HIPB(hipMemcpyAsync(sl.d_packed, src_rows, (size_t)n * sw * 4, hipMemcpyHostToDevice, ix->s_copy));
+        if (f.tight) {   // fewer bytes over the link: the rows arrive tight and are widened on the device
+            if (sl.cap_tight < (size_t)n * f.sb) {
+                if (sl.d_tight) (void)hipFree(sl.d_tight);
+                sl.d_tight = nullptr; sl.cap_tight = 0;
+                CQ_HIPB(hipMalloc((void **)&sl.d_tight, (size_t)n * f.sb));
+                sl.cap_tight = (size_t)n * f.sb;
+            }
+            CQ_HIPB(hipMemcpyAsync(sl.d_tight, f.tight + (size_t)c0 * f.sb, (size_t)n * f.sb, hipMemcpyHostToDevice, ix->s_copy));
+        } else
+            CQ_HIPB(hipMemcpyAsync(sl.d_packed, src_rows, (size_t)n * sw * 4, hipMemcpyHostToDevice, ix->s_copy));
         CQ_HIPB(hipEventRecord(sl.copied, ix->s_copy));
         // the small copy of the lengths goes down its own queue: behind the rows it would put a bubble between
         // every two large transfers
@@ -705,10 +739,16 @@ int classify_range(cq_index *ix, int mode, const Feed &f, uint64_t lo, uint64_t 
             // flight -- in front of them the scan delayed every transfer (measured: 1 540 -> 1 325 Mreads/s).
             uint32_t longest = 0;
             for (uint64_t r = 0; r < n; r++) longest = std::max<uint32_t>(longest, src_lens[r]);
-            if (longest > sw * 16u) { rc = fail(CQ_ERR_ARG, "cq_query_packed: a length exceeds 16 x stride_words bases"); break; }
+            if (longest > (f.tight ? f.sb * 4u : sw * 16u)) { rc = fail(CQ_ERR_ARG, "cq_query_packed: a length exceeds what a row of this stride holds"); break; }
             max_len = std::max<uint64_t>(max_len, longest);
         }
-        CQ_HIPB(hipStreamWaitEvent(ix->s_comp, sl.copied, 0));
+        if (f.tight) {   // widen on a queue of its own: in front of the classify kernel it would cost the chunk ~0.1 ms
+            CQ_HIPB(hipStreamWaitEvent(ix->s_widen, sl.copied, 0));
+            CQ_HIPB(cq::launch_widen_rows(sl.d_tight, f.sb, sl.d_packed, sw, n, ix->s_widen));
+            CQ_HIPB(hipEventRecord(sl.widened, ix->s_widen));
+            CQ_HIPB(hipStreamWaitEvent(ix->s_comp, sl.widened, 0));
+        } else
+            CQ_HIPB(hipStreamWaitEvent(ix->s_comp, sl.copied, 0));
         CQ_HIPB(hipStreamWaitEvent(ix->s_comp, sl.copied_lens, 0));
         rc = cq_query_device(ix, mode, sl.d_packed, sl.d_lens, n, sw, (uint32_t)max_len, n_genomes, ix->d_ctr, d_rc,
                              ix->s_comp);
@@ -720,6 +760,7 @@ int classify_range(cq_index *ix, int mode, const Feed &f, uint64_t lo, uint64_t 
     if (rc != CQ_OK) {   // an error may have left copies from the caller's memory in flight with no kernel behind them
         (void)hipStreamSynchronize(ix->s_copy);
         (void)hipStreamSynchronize(ix->s_copy2);
+        (void)hipStreamSynchronize(ix->s_widen);
     }
     return rc;
 }
@@ -842,6 +883,22 @@ int cq_query_packed(cq_index *ix, int mode, const uint32_t *packed, const uint8_
     f.packed = packed;
     f.lens = lens;
     f.sw = stride_words;
+    f.max_len = max_len;
+    return query_one(ix, mode, f, n_reads, n_genomes, out);
+}
+
+int cq_query_packed_tight(cq_index *ix, int mode, const uint8_t *packed, const uint8_t *lens, uint64_t n_reads,
+                          uint32_t stride_bytes, uint32_t max_len, uint32_t n_genomes, cq_counts *out)
+{
+    if (!ix || !out || (n_reads && (!packed || !lens))) return fail(CQ_ERR_ARG, "cq_query_packed_tight: NULL argument");
+    if (stride_bytes == 0 || stride_bytes > 64) return fail(CQ_ERR_ARG, "cq_query_packed_tight: bad stride");
+    int rc = query_checks(ix, mode, n_genomes, out, "cq_query_packed_tight");
+    if (rc != CQ_OK) return rc;
+    Feed f;
+    f.tight = packed;
+    f.lens = lens;
+    f.sb = stride_bytes;
+    f.sw = (stride_bytes + 3) / 4;
     f.max_len = max_len;
     return query_one(ix, mode, f, n_reads, n_genomes, out);
 }
@@ -1123,6 +1180,20 @@ int cq_multi_query_packed(cq_multi *m, int mode, const uint32_t *packed, const u
     f.sw = stride_words;
     f.max_len = max_len;
     return multi_query(m, mode, f, n_reads, n_genomes, out, "cq_multi_query_packed");
+}
+
+int cq_multi_query_packed_tight(cq_multi *m, int mode, const uint8_t *packed, const uint8_t *lens, uint64_t n_reads,
+                                uint32_t stride_bytes, uint32_t max_len, uint32_t n_genomes, cq_counts *out)
+{
+    if (!m || !out || (n_reads && (!packed || !lens))) return fail(CQ_ERR_ARG, "cq_multi_query_packed_tight: NULL argument");
+    if (stride_bytes == 0 || stride_bytes > 64) return fail(CQ_ERR_ARG, "cq_multi_query_packed_tight: bad stride");
+    Feed f;
+    f.tight = packed;
+    f.lens = lens;
+    f.sb = stride_bytes;
+    f.sw = (stride_bytes + 3) / 4;
+    f.max_len = max_len;
+    return multi_query(m, mode, f, n_reads, n_genomes, out, "cq_multi_query_packed_tight");
 }
 
 }  // extern "C"

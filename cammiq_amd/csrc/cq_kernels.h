@@ -55,5 +55,10 @@ hipError_t launch_classify(const DevIndex &ix, QueryArgs a, int n_cus, hipStream
 hipError_t launch_accumulate(uint64_t *dst64, const uint64_t *src64, uint64_t n64, uint32_t *dst32,
                              const uint32_t *src32, uint64_t n32, hipStream_t stream);
 
+// Tight rows (stride of sb bytes, most significant base first) -> word rows of sw words, zero-filled past the
+// row: what cq_query_packed_tight runs on every chunk after its H2D copy (include/cammiq_hip.h).
+hipError_t launch_widen_rows(const uint8_t *tight, uint32_t sb, uint32_t *rows, uint32_t sw, uint64_t n_reads,
+                             hipStream_t stream);
+
 }  // namespace cq
 #endif

@@ -109,7 +109,76 @@ void pack_range(const uint8_t *bases, const uint64_t *offsets, uint64_t lo, uint
     *skipped = sk;
 }
 
+// Tight rows: the same 2-bit string at a stride of whole bytes (base j in byte j/4, first base in the top bits):
+// a word row written most significant byte first, cut after stride_bytes.
+void pack_range_tight(const uint8_t *bases, const uint64_t *offsets, uint64_t lo, uint64_t hi, uint32_t h,
+                      uint32_t sb, uint8_t *packed, uint8_t *lens, uint64_t *skipped)
+{
+    uint64_t sk = 0;
+    const uint32_t sw = (sb + 3) / 4;
+    for (uint64_t r = lo; r < hi; r++) {
+        uint32_t row[16];
+        const uint64_t one[2] = {offsets[r], offsets[r + 1]};
+        uint64_t s1 = 0;
+        const uint64_t len = one[1] - one[0];
+        if (len > (uint64_t)sb * 4) { memset(row, 0, sizeof row); lens[r] = 0; s1 = 1; }   // does not fit the tight row
+        else pack_range(bases, one, 0, 1, h, sw, row, lens + r, &s1);   // writes row[0 .. sw), lens[r]
+        sk += s1;
+        uint8_t *dst = packed + r * (uint64_t)sb;
+        for (uint32_t k = 0; k < sb; k++) dst[k] = (uint8_t)(row[k >> 2] >> (24u - 8u * (k & 3u)));
+    }
+    *skipped = sk;
+}
+
+template <class Fn>
+uint64_t run_threads(uint64_t n_reads, Fn &&fn)
+{
+    unsigned hw = std::thread::hardware_concurrency();
+    unsigned nt = std::max(1u, std::min(hw ? hw : 1u, 32u));
+    if (n_reads < 65536) nt = 1;
+    std::vector<uint64_t> sk(nt, 0);
+    if (nt == 1) fn(0, n_reads, &sk[0]);
+    else {
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < nt; t++) th.emplace_back([&, t] { fn(n_reads * t / nt, n_reads * (t + 1) / nt, &sk[t]); });
+        for (auto &x : th) x.join();
+    }
+    uint64_t total = 0;
+    for (auto v : sk) total += v;
+    return total;
+}
+
 }  // namespace
+
+extern "C" uint32_t cq_pack_stride_bytes(uint32_t max_len)
+{
+    if (max_len > 255) max_len = 255;
+    const uint32_t b = (max_len + 3) / 4;
+    return b ? b : 1;
+}
+
+extern "C" int cq_pack_read_tight(const uint8_t *seq, uint32_t len, uint32_t hash_len, uint32_t stride_bytes, uint8_t *row,
+                                  uint8_t *len_out)
+{
+    if (!row || !len_out || stride_bytes == 0 || stride_bytes > 64 || (!seq && len)) return CQ_ERR_ARG;
+    const uint64_t off[2] = {0, len};
+    uint64_t sk = 0;
+    pack_range_tight(seq, off, 0, 1, hash_len, stride_bytes, row, len_out, &sk);
+    return CQ_OK;
+}
+
+extern "C" int cq_pack_reads_tight(const uint8_t *bases, const uint64_t *offsets, uint64_t n_reads, uint32_t hash_len,
+                                   uint32_t stride_bytes, uint8_t *packed, uint8_t *lens, uint64_t *n_skipped)
+{
+    if ((!bases && n_reads && offsets && offsets[n_reads] != 0) || !offsets || !packed || !lens ||
+        stride_bytes == 0 || stride_bytes > 64)
+        return CQ_ERR_ARG;
+    const uint64_t total = run_threads(n_reads, [&](uint64_t lo, uint64_t hi, uint64_t *sk) {
+        pack_range_tight(bases, offsets, lo, hi, hash_len, stride_bytes, packed, lens, sk);
+    });
+    if (n_skipped) *n_skipped = total;
+    return CQ_OK;
+}
 
 extern "C" uint32_t cq_pack_stride_words(uint32_t max_len)
 {

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define CQ_ABI_VERSION 2
+#define CQ_ABI_VERSION 3
 
 typedef enum cq_status {
     CQ_OK = 0,
@@ -187,6 +187,24 @@ int cq_pack_reads(const uint8_t *bases, const uint64_t *offsets, uint64_t n_read
 int cq_pack_read(const uint8_t *seq, uint32_t len, uint32_t hash_len, uint32_t stride_words, uint32_t *row,
                  uint8_t *len_out);
 
+/*
+ * Tight rows: the same 2-bit string at a stride of whole BYTES -- ceil(max_len / 4), 1..64: 25 bytes for a
+ * 100-bp read instead of 28 -- for reads that have to cross the host link (H2D is what bounds a host-fed
+ * query: 57 GB/s against 2.2 G reads/s of kernel).  Base j of a read goes to byte j/4, bits
+ * [7-2(j%4) : 6-2(j%4)]; row r starts at packed + r * stride_bytes, no alignment.  cq_query_packed_tight copies
+ * the tight rows to the GPU and widens them there to the word rows the kernels take (one small kernel per
+ * chunk); everything else is cq_query_packed.  A length above 4 * stride_bytes is CQ_ERR_ARG.
+ */
+uint32_t cq_pack_stride_bytes(uint32_t max_len);
+int cq_pack_reads_tight(const uint8_t *bases, const uint64_t *offsets, uint64_t n_reads,
+                        uint32_t hash_len, uint32_t stride_bytes, uint8_t *packed, uint8_t *lens,
+                        uint64_t *n_skipped);
+int cq_pack_read_tight(const uint8_t *seq, uint32_t len, uint32_t hash_len, uint32_t stride_bytes, uint8_t *row,
+                       uint8_t *len_out);
+int cq_query_packed_tight(cq_index *idx, int mode, const uint8_t *packed, const uint8_t *lens,
+                          uint64_t n_reads, uint32_t stride_bytes, uint32_t max_len, uint32_t n_genomes,
+                          cq_counts *out);
+
 /* Number of uint64 in the device counter block for n_genomes:
  * [cnt_u[G+1] | cnt_d[G+1] | nundet nconf nskipped flags nslow 0 0 0].  flags != 0: increments of the
  * SC pair map were lost (map full).  Every word adds up across GPUs, flags included. */
@@ -249,6 +267,9 @@ int cq_multi_query(cq_multi *m, int mode, const uint8_t *bases, const uint64_t *
 int cq_multi_query_packed(cq_multi *m, int mode, const uint32_t *packed, const uint8_t *lens,
                           uint64_t n_reads, uint32_t stride_words, uint32_t max_len, uint32_t n_genomes,
                           cq_counts *out);
+int cq_multi_query_packed_tight(cq_multi *m, int mode, const uint8_t *packed, const uint8_t *lens,
+                                uint64_t n_reads, uint32_t stride_bytes, uint32_t max_len, uint32_t n_genomes,
+                                cq_counts *out);
 void cq_multi_free(cq_multi *m);
 
 /* (2) One process per GPU (torchrun / mpirun style): rank 0 makes an id, the launcher's own

@@ -56,6 +56,16 @@ int main(int argc, char **argv)
         c.cnt_u = c1; c.cnt_d = c2;
         if (cq_query_packed(ix, CQ_MODE_SC, packed, &len, 1, 4, 32, 4, &c) != CQ_ERR_NO_DEVICE) return 18;
         if (cq_multi_size(NULL) != 0 || cq_multi_index(NULL, 0) != NULL) return 19;
+        {   /* tight rows (ABI 3): 32 bases = 8 bytes, most significant base first */
+            uint8_t trow[8] = {0}, tl = 0;
+            int k;
+            if (cq_pack_stride_bytes(100) != 25 || cq_pack_stride_bytes(32) != 8) return 20;
+            if (cq_pack_read_tight(read, 32, 1, 8, trow, &tl) != CQ_OK || tl != 32) return 21;
+            for (k = 0; k < 8; k++) if (trow[k] != 0x1B) return 22;
+            if (cq_pack_reads_tight(read, offs, 1, info.hash_len, 8, trow, &tl, &skipped) != CQ_OK || tl != 32 || skipped != 0) return 23;
+            if (cq_query_packed_tight(ix, CQ_MODE_SC, trow, &tl, 1, 8, 32, 4, &c) != CQ_ERR_NO_DEVICE) return 24;
+            if (cq_multi_query_packed_tight(NULL, CQ_MODE_SC, trow, &tl, 1, 8, 32, 4, &c) != CQ_ERR_ARG) return 25;
+        }
     }
     printf("ok hash_len %u leaves %llu+%llu keys %llu\n", info.hash_len, (unsigned long long)info.n_leaves[0],
            (unsigned long long)info.n_leaves[1], (unsigned long long)info.n_keys);

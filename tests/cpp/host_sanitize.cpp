@@ -60,6 +60,21 @@ int main(int argc, char **argv)
         if (cq_pack_read(bases.data() + offs[r], (uint32_t)(len > 0xFFFFFFFFull ? 0 : len), 1, w, row.data(), &lo) != CQ_OK) { printf("PACK_READ FAILED\n"); return 1; }
         if (lo != lens[r] && !(lens[r] == 0 && len < img.hash_len)) { printf("PACK_READ LEN %u vs %u\n", lo, lens[r]); return 1; }
     }
+    // and as tight rows (cq_pack_read_tight / cq_pack_reads_tight), again with exact allocations
+    for (uint64_t r = 0; r < n; r++) {
+        const uint64_t len = offs[r + 1] - offs[r];
+        const uint32_t sb = cq_pack_stride_bytes(len > 255 ? 255 : (uint32_t)len);
+        std::vector<uint8_t> row(sb);
+        uint8_t lo = 7;
+        if (cq_pack_read_tight(bases.data() + offs[r], (uint32_t)(len > 0xFFFFFFFFull ? 0 : len), 1, sb, row.data(), &lo) != CQ_OK) { printf("PACK_READ_TIGHT FAILED\n"); return 1; }
+        if (lo != lens[r] && !(lens[r] == 0 && len < img.hash_len)) { printf("PACK_READ_TIGHT LEN %u vs %u\n", lo, lens[r]); return 1; }
+    }
+    {
+        const uint32_t sb = cq_pack_stride_bytes(100);
+        std::vector<uint8_t> tight(n * sb + 1), tl(n + 1);
+        uint64_t tsk = 0;
+        if (cq_pack_reads_tight(bases.data(), offs.data(), n, img.hash_len, sb, tight.data(), tl.data(), &tsk) != CQ_OK) { printf("PACK_READS_TIGHT FAILED\n"); return 1; }
+    }
     // meta files next to index_u (glue header): whatever is there -- present, absent or damaged -- must parse cleanly
     {
         std::vector<MetaGenome> genomes(std::min<uint64_t>((uint64_t)img.max_refid + 2, 100000));   // a damaged index may carry any refID

@@ -36,7 +36,7 @@ def test_single_gpu_line():
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and j["parity_checked_reads"] == 20000
     o = j["outcome"]
     assert o["reads"] == 2 * 200000 and o["nskipped"] == 0
-    assert j["host_fed"]["Mreads_s"] > 0 and j["host_fed"]["bytes_per_read_on_the_wire"] == 29
+    assert j["host_fed"]["Mreads_s"] > 0 and j["host_fed"]["bytes_per_read_on_the_wire"] == 26
 
 
 def test_two_ranks_rehearsal_over_gloo():

@@ -38,7 +38,7 @@ def _draw(seed):
              frac_random=r.choice([0.0, 0.1, 0.5]), lower_frac=r.choice([0.0, 0.2]),
              n_bad=r.choice([0, 0, 3, 40]), unique_only=r.random() < 0.2,
              extra_genomes=r.choice([0, 0, 1, 37, 8191, 9000]),          # ids the index never names; 9000 > LDS histogram
-             route=r.choice(["ascii", "ascii", "packed", "multi", "multi_packed"]),
+             route=r.choice(["ascii", "ascii", "packed", "tight", "multi", "multi_packed", "multi_tight"]),
              env={})
     lo = max(h, 1)
     shape = r.choice(["fixed", "ragged", "short", "long"])
@@ -114,6 +114,10 @@ def _run_world(w, tmpdir):
                 assert sk == n_bad, f"packer skipped {sk}, want {n_bad}"
                 ml = int(lens.max()) if len(lens) else 0
                 got = ix.query_packed(packed, lens, ml, G, mode=mode)
+            elif w["route"].endswith("tight"):
+                tight, lens, sk = cq.pack_reads_tight(bm, om, w["h"])
+                assert sk == n_bad, f"tight packer skipped {sk}, want {n_bad}"
+                got = ix.query_packed_tight(tight, lens, 0, G, mode=mode)
             else:
                 got = ix.query(bm, om, G, mode=mode)
                 assert got["nskipped"] == n_bad, f"nskipped {got['nskipped']}, want {n_bad}"
@@ -141,7 +145,7 @@ def _draw_generator(seed):
              genome_len=max(markers * me // G, 600), frac_deep=r.choice([0.0, 0.07, 0.5]),
              pair_share=r.choice([0.0, 0.1, 0.5]), block=r.choice([256, 2048, 8192]),
              n_reads=r.choice([20_000, 60_000]), err=r.choice([0.0, 0.01, 0.05]), frac_random=r.choice([0.0, 0.1, 0.6]),
-             route=r.choice(["ascii", "packed", "multi", "multi_packed"]), env={})
+             route=r.choice(["ascii", "packed", "tight", "multi", "multi_packed", "multi_tight"]), env={})
     w["rl"] = r.choice([h, 50, 75, 100, 100, 150, 250, 255])
     w["rl"] = min(max(w["rl"], h), w["genome_len"])
     if r.random() < 0.4:
@@ -179,6 +183,10 @@ def _run_generator_world(w, tmpdir):
                 packed, lens, sk = cq.pack_reads(b, o, w["h"])
                 assert sk == 0
                 got = ix.query_packed(packed, lens, w["rl"], G, mode=mode, pair_cap=1 << 18)
+            elif w["route"].endswith("tight"):
+                tight, lens, sk = cq.pack_reads_tight(b, o, w["h"])
+                assert sk == 0
+                got = ix.query_packed_tight(tight, lens, w["rl"], G, mode=mode, pair_cap=1 << 18)
             else:
                 got = ix.query(b, o, G, mode=mode, pair_cap=1 << 18)
                 assert got["nskipped"] == 0

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name), f"{name} declared in cammiq_hip.h but not exported"
     assert declared == set(binding.SIGNATURES), (declared ^ set(binding.SIGNATURES))
-    assert binding.lib().cq_abi_version() == 2
+    assert binding.lib().cq_abi_version() == 3
 
 
 def test_oracle_is_not_linked_into_the_product():
@@ -408,3 +408,37 @@ def test_pack_read_single_row_equals_batch_packer():
         ok = all(c in b"ACGTacgt" for c in r) and 1 <= len(r) <= 255
         assert ln.value == (len(r) if ok else 0)
     assert L.cq_pack_read(None, 5, 1, sw, None, None) == -1
+
+
+def test_tight_rows_are_the_word_rows_cut_to_whole_bytes():
+    """cq_pack_reads_tight / cq_pack_read_tight: base j in byte j/4, first base on top -- the word row written most
+    significant byte first and cut after ceil(len_max / 4) bytes (25 bytes per 100-bp read over the host link).
+    Every byte value, every length 0..300, strides that do not hold the longest read, guard bytes around each row."""
+    import ctypes as C
+    assert [cq.stride_bytes(x) for x in (0, 1, 4, 5, 100, 150, 255, 9999)] == [1, 1, 1, 2, 25, 38, 64, 64]
+    rng = np.random.default_rng(11)
+    reads = [bytes(rng.choice(np.frombuffer(b"ACGTacgt", np.uint8), size=n)) for n in list(range(0, 301, 1))]
+    reads += [b"ACGTN" * 7, b"ACGT\xe6ACGT" * 4, bytes(range(256))[:200]]
+    b, o = synth.concat_reads(reads)
+    for h in (1, 26):
+        words, wl, wsk = cq.pack_reads(b, o, h)
+        for sb in (64, 25, 7):
+            tight, tl, tsk = cq.pack_reads_tight(b, o, h, sb=sb)
+            fits = np.array([len(r) <= 4 * sb for r in reads])
+            assert np.array_equal(tl, np.where(fits, wl, 0))
+            assert tsk == wsk + int((~fits & (wl > 0)).sum())
+            be = words.astype(">u4").view(np.uint8).reshape(len(reads), -1)[:, :sb]
+            assert np.array_equal(tight[tl > 0], be[tl > 0])
+            assert not tight[tl == 0].any()                                  # skipped reads leave zero rows
+    L = binding.lib()
+    tight, tl, _ = cq.pack_reads_tight(b, o, 26)
+    for i, r in enumerate(reads):
+        sb = cq.stride_bytes(min(len(r), 255))
+        row = np.full(sb + 2, 0xA5, np.uint8)                                # one guard byte on either side
+        ln = C.c_uint8(77)
+        buf = np.frombuffer(r, np.uint8)
+        assert L.cq_pack_read_tight(buf.ctypes.data_as(C.c_void_p), len(r), 26, sb, row[1:].ctypes.data_as(C.c_void_p), C.byref(ln)) == 0
+        assert row[0] == 0xA5 and row[-1] == 0xA5, i
+        assert ln.value == tl[i] and np.array_equal(row[1:-1], tight[i, :sb]), i
+    assert L.cq_pack_read_tight(None, 5, 1, 25, None, None) == -1
+    assert L.cq_pack_reads_tight(None, None, 0, 26, 0, None, None, None) == -1

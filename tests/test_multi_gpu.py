@@ -48,6 +48,13 @@ def test_multi_query_equals_single_device(tmp_path, devices):
     # pre-packed rows through the same shards
     packed, lens, _ = cq.pack_reads(b, o, one.hash_len)
     assert_same(m.query_packed(packed, lens, 200, G), ref, "multi packed")
+    tight, tlens, _ = cq.pack_reads_tight(b, o, one.hash_len)           # 50 bytes per read instead of 52
+    assert tight.shape[1] == 50
+    for mode in (cq.MODE_P, cq.MODE_SC):
+        got = m.query_packed_tight(tight, tlens, 200, G, mode=mode)
+        want = one.query(b, o, G, mode=mode)
+        assert_same(got, want, f"multi tight mode {mode}", rcount=(mode == cq.MODE_P))
+        assert got["pairs"] == want["pairs"]
     # fewer reads than shards, and none at all
     for k in (0, 1, len(devices)):
         bb, oo = synth.concat_reads(reads[:k])
@@ -83,6 +90,45 @@ def test_query_packed_equals_query_and_kernel_times(tmp_path):
     with pytest.raises(cq.CammiqError) as e:
         ix.query_packed(narrow, bad, 64, g["G"])
     assert e.value.code == -1
+
+
+@pytest.mark.parametrize("rl", [(26, 255), 100, 27, 150])
+def test_tight_rows_equal_ascii_reads(tmp_path, rl):
+    """cq_query_packed_tight: rows at a byte stride cross the link and are widened on the device.  Ragged and fixed
+    lengths (strides of 64, 25, 7 and 38 bytes: every alignment of a row start), reads outside the parity domain in
+    between, more than one 2 M-read chunk, pinned and pageable inputs, a stride too small for a length."""
+    gen = synth.clade_genomes(91, 3, 3, 3000, 0.03)
+    u, d = synth.select_markers(gen, 26, 40, keep_every=2, seed=4)
+    pu, pd = build_index(tmp_path, u, d, 26)
+    G = len(gen)
+    base = synth.simulate_reads(gen, 7001, rl, 0.01, 5, frac_random=0.1)
+    hi = rl if isinstance(rl, int) else rl[1]
+    bad = [b"ACGT", gen[0][:hi - 1] + b"N", b""]
+    reads = base[:3000] + bad + base[3000:]
+    reads = reads * (301 if rl == 100 else 1)              # 100 bp: 2.1 M reads = two chunks, the second one short
+    b, o = synth.concat_reads(reads)
+    ix = cq.Index(pu, pd, device=0)
+    tight, lens, sk = cq.pack_reads_tight(b, o, ix.hash_len)
+    assert tight.shape[1] == cq.stride_bytes(hi) and sk == len(bad) * (len(reads) // len(base + bad))
+    for mode in (cq.MODE_P, cq.MODE_SC):
+        want = ix.query(b, o, G, mode=mode)
+        got = ix.query_packed_tight(tight, lens, hi, G, mode=mode)
+        assert_same(got, want, f"tight rl={rl} mode={mode}", rcount=(mode == cq.MODE_P))
+        assert got["pairs"] == want["pairs"] and got["nskipped"] == want["nskipped"] == sk
+    if rl != 100:
+        ref = oracle_lib.OracleIndex(pu, pd).query(*synth.concat_reads(base), G, nthreads=8)
+        assert_same(ix.query_packed_tight(tight, lens, 0, G), ref, f"tight vs oracle rl={rl}")
+    pt = cq.host_array(tight.size, np.uint8).reshape(tight.shape)
+    pl = cq.host_array(lens.size, np.uint8)
+    pt[:] = tight
+    pl[:] = lens
+    assert_same(ix.query_packed_tight(pt, pl, hi, G), ix.query(b, o, G), "tight, pinned")
+    if tight.shape[1] > 7:
+        bad_l = lens.copy()
+        bad_l[1] = 4 * 7 + 1
+        with pytest.raises(cq.CammiqError) as e:
+            ix.query_packed_tight(np.ascontiguousarray(tight[:, :7]), bad_l, 0, G)
+        assert e.value.code == -1
 
 
 def test_large_rcount_comes_back_through_the_bounce_buffers(tmp_path):
