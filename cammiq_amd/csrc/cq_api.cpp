@@ -695,12 +695,22 @@ int classify_range(cq_index *ix, int mode, const Feed &f, uint64_t lo, uint64_t 
         const uint64_t n = std::min(kChunk, hi - c0);
         uint64_t max_len = f.max_len;
         uint32_t sw = f.sw;
-        if (ascii) {
-            max_len = 0;
-            for (uint64_t r = c0; r < c0 + n; r++) {
-                const uint64_t l = f.offsets[r + 1] - f.offsets[r];
-                if (l <= 255 && l > max_len) max_len = l;
-            }
+        if (ascii) {   // longest read of the chunk (sizes the rows): a few threads, one would take ~1 ms per 2 M reads
+            const unsigned nt = n >= (1u << 18) ? 8u : 1u;
+            uint64_t part[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            auto scan = [&](unsigned t) {
+                uint64_t m = 0;
+                for (uint64_t r = c0 + n * t / nt, e = c0 + n * (t + 1) / nt; r < e; r++) {
+                    const uint64_t l = f.offsets[r + 1] - f.offsets[r];
+                    if (l <= 255 && l > m) m = l;
+                }
+                part[t] = m;
+            };
+            std::vector<std::thread> th;
+            for (unsigned t = 1; t < nt; t++) th.emplace_back(scan, t);
+            scan(0);
+            for (auto &x : th) x.join();
+            max_len = *std::max_element(part, part + nt);
             sw = cq_pack_stride_words((uint32_t)max_len);
         }
         if (sl.done) { CQ_HIPB(hipEventSynchronize(sl.done)); }   // the kernel that last used this slot

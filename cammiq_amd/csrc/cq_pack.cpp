@@ -80,16 +80,106 @@ __attribute__((target("bmi2"))) bool pack_row_bmi2(const uint8_t *s, uint32_t le
     }
     return !(sb & 0x80u);
 }
+
+// AVX2: 32 ASCII bases -> 8 bytes of the 2-bit string per step (first base in the top bits of the first byte).
+// (c & 0xDF) >> 1 & 3 maps A,C,G,T (either case) to 0,1,3,2; x ^ (x >> 1) turns that into 0,1,2,3; a byte that is
+// not ACGTacgt is found by looking the letter up again from its code.  Two multiply-adds put four codes into one
+// byte (b0*64 + b1*16 + b2*4 + b3), a byte shuffle collects the eight bytes.  `out` must be zeroed for
+// ceil(len / 4) bytes; the bases behind the last full block of 32 go through the scalar table.
+__attribute__((target("avx2"))) bool pack_bytes_avx2(const uint8_t *s, uint32_t len, uint8_t *out)
+{
+    const __m256i kDF = _mm256_set1_epi8((char)0xDF), k3 = _mm256_set1_epi8(3), k1 = _mm256_set1_epi8(1);
+    const __m256i lut = _mm256_setr_epi8('A', 'C', 'G', 'T', 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0,
+                                         'A', 'C', 'G', 'T', 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0);
+    const __m256i m4_1 = _mm256_set1_epi16(0x0104), m16_1 = _mm256_set1_epi32(0x00010010);
+    const __m256i pick = _mm256_setr_epi8(0, 4, 8, 12, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1,
+                                          0, 4, 8, 12, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1);
+    __m256i bad = _mm256_setzero_si256();
+    uint32_t j = 0;
+    for (; j + 32 <= len; j += 32) {
+        const __m256i v = _mm256_loadu_si256((const __m256i *)(s + j));
+        const __m256i u = _mm256_and_si256(v, kDF);
+        const __m256i r = _mm256_and_si256(_mm256_srli_epi16(u, 1), k3);
+        const __m256i code = _mm256_xor_si256(r, _mm256_and_si256(_mm256_srli_epi16(r, 1), k1));
+        bad = _mm256_or_si256(bad, _mm256_xor_si256(_mm256_shuffle_epi8(lut, code), u));
+        const __m256i m = _mm256_madd_epi16(_mm256_maddubs_epi16(code, m4_1), m16_1);
+        const __m256i p = _mm256_shuffle_epi8(m, pick);
+        const uint32_t lo = (uint32_t)_mm_cvtsi128_si32(_mm256_castsi256_si128(p));
+        const uint32_t hi = (uint32_t)_mm_cvtsi128_si32(_mm256_extracti128_si256(p, 1));
+        memcpy(out + (j >> 2), &lo, 4);
+        memcpy(out + (j >> 2) + 4, &hi, 4);
+    }
+    if (len - j >= 8) {   // a longer tail: one more block on a copy padded with 'A' (code 0: no bits, always valid)
+        alignas(32) uint8_t pad[32];
+        memset(pad, 'A', 32);
+        memcpy(pad, s + j, len - j);
+        const __m256i v = _mm256_load_si256((const __m256i *)pad);
+        const __m256i u = _mm256_and_si256(v, kDF);
+        const __m256i r = _mm256_and_si256(_mm256_srli_epi16(u, 1), k3);
+        const __m256i code = _mm256_xor_si256(r, _mm256_and_si256(_mm256_srli_epi16(r, 1), k1));
+        bad = _mm256_or_si256(bad, _mm256_xor_si256(_mm256_shuffle_epi8(lut, code), u));
+        const __m256i m = _mm256_madd_epi16(_mm256_maddubs_epi16(code, m4_1), m16_1);
+        const __m256i p = _mm256_shuffle_epi8(m, pick);
+        uint8_t o8[8];
+        const uint32_t lo = (uint32_t)_mm_cvtsi128_si32(_mm256_castsi256_si128(p));
+        const uint32_t hi = (uint32_t)_mm_cvtsi128_si32(_mm256_extracti128_si256(p, 1));
+        memcpy(o8, &lo, 4);
+        memcpy(o8 + 4, &hi, 4);
+        memcpy(out + (j >> 2), o8, (len - j + 3) / 4);   // only the bytes this read owns (a tight row ends there)
+        j = len;
+    }
+    if (!_mm256_testz_si256(bad, bad)) return false;
+    uint32_t sb = 0;
+    for (; j < len; j++) {
+        const uint32_t c = kSym.t[s[j]];
+        sb |= c;
+        out[j >> 2] |= (uint8_t)((c & 3u) << (6u - 2u * (j & 3u)));
+    }
+    return !(sb & 0x80u);
+}
 #endif
+
+// Which packer runs: 2 = AVX2, 1 = BMI2 (PEXT), 0 = scalar table; CAMMIQ_PACK_ISA=scalar|bmi2|avx2 caps it (tests).
+int pack_isa()
+{
+    static const int isa = [] {
+        int best = 0;
+#if defined(__x86_64__)
+        if (__builtin_cpu_supports("bmi2")) best = 1;
+        if (__builtin_cpu_supports("avx2")) best = 2;
+#endif
+        if (const char *v = getenv("CAMMIQ_PACK_ISA")) {
+            const int want = !strcmp(v, "scalar") ? 0 : !strcmp(v, "bmi2") ? 1 : 2;
+            if (want < best) best = want;
+        }
+        return best;
+    }();
+    return isa;
+}
+
+// One read -> the 2-bit string as bytes (most significant base first) in out[0 .. ceil(len/4)), zero behind it up to
+// n_out bytes.  false: a byte that is not ACGTacgt.
+bool pack_bytes(const uint8_t *s, uint32_t len, uint8_t *out, uint32_t n_out, int isa)
+{
+    memset(out, 0, n_out);
+#if defined(__x86_64__)
+    if (isa == 2) return pack_bytes_avx2(s, len, out);
+#endif
+    uint32_t row[16] = {0};
+    bool ok;
+#if defined(__x86_64__)
+    ok = isa == 1 ? pack_row_bmi2(s, len, row) : pack_row_scalar(s, len, row);
+#else
+    ok = pack_row_scalar(s, len, row);
+#endif
+    for (uint32_t k = 0; k < (len + 3) / 4; k++) out[k] = (uint8_t)(row[k >> 2] >> (24u - 8u * (k & 3u)));
+    return ok;
+}
 
 void pack_range(const uint8_t *bases, const uint64_t *offsets, uint64_t lo, uint64_t hi, uint32_t h,
                 uint32_t sw, uint32_t *packed, uint8_t *lens, uint64_t *skipped)
 {
-#if defined(__x86_64__)
-    const bool fast = __builtin_cpu_supports("bmi2");
-#else
-    const bool fast = false;
-#endif
+    const int isa = pack_isa();
     uint64_t sk = 0;
     for (uint64_t r = lo; r < hi; r++) {
         uint32_t *row = packed + r * sw;
@@ -98,11 +188,19 @@ void pack_range(const uint8_t *bases, const uint64_t *offsets, uint64_t lo, uint
         if (len < h || len > 255 || len > (uint64_t)sw * 16) { lens[r] = 0; sk++; continue; }
         const uint8_t *s = bases + offsets[r];
         bool ok;
+        if (isa == 2) {   // bytes first (the AVX2 packer's output order), then words: most significant byte first
+            uint8_t tmp[64];
+            ok = pack_bytes(s, (uint32_t)len, tmp, 64, isa);
+            for (uint32_t w = 0; w < sw; w++) {
+                uint32_t v;
+                memcpy(&v, tmp + 4 * w, 4);
+                row[w] = __builtin_bswap32(v);
+            }
+        }
 #if defined(__x86_64__)
-        ok = fast ? pack_row_bmi2(s, (uint32_t)len, row) : pack_row_scalar(s, (uint32_t)len, row);
-#else
-        ok = pack_row_scalar(s, (uint32_t)len, row);
+        else if (isa == 1) ok = pack_row_bmi2(s, (uint32_t)len, row);
 #endif
+        else ok = pack_row_scalar(s, (uint32_t)len, row);
         if (!ok) { memset(row, 0, (size_t)sw * 4); lens[r] = 0; sk++; }
         else lens[r] = (uint8_t)len;
     }
@@ -114,18 +212,14 @@ void pack_range(const uint8_t *bases, const uint64_t *offsets, uint64_t lo, uint
 void pack_range_tight(const uint8_t *bases, const uint64_t *offsets, uint64_t lo, uint64_t hi, uint32_t h,
                       uint32_t sb, uint8_t *packed, uint8_t *lens, uint64_t *skipped)
 {
+    const int isa = pack_isa();
     uint64_t sk = 0;
-    const uint32_t sw = (sb + 3) / 4;
     for (uint64_t r = lo; r < hi; r++) {
-        uint32_t row[16];
-        const uint64_t one[2] = {offsets[r], offsets[r + 1]};
-        uint64_t s1 = 0;
-        const uint64_t len = one[1] - one[0];
-        if (len > (uint64_t)sb * 4) { memset(row, 0, sizeof row); lens[r] = 0; s1 = 1; }   // does not fit the tight row
-        else pack_range(bases, one, 0, 1, h, sw, row, lens + r, &s1);   // writes row[0 .. sw), lens[r]
-        sk += s1;
         uint8_t *dst = packed + r * (uint64_t)sb;
-        for (uint32_t k = 0; k < sb; k++) dst[k] = (uint8_t)(row[k >> 2] >> (24u - 8u * (k & 3u)));
+        const uint64_t len = offsets[r + 1] - offsets[r];
+        if (len < h || len > 255 || len > (uint64_t)sb * 4) { memset(dst, 0, sb); lens[r] = 0; sk++; continue; }
+        if (!pack_bytes(bases + offsets[r], (uint32_t)len, dst, sb, isa)) { memset(dst, 0, sb); lens[r] = 0; sk++; }
+        else lens[r] = (uint8_t)len;
     }
     *skipped = sk;
 }

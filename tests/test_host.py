@@ -442,3 +442,20 @@ def test_tight_rows_are_the_word_rows_cut_to_whole_bytes():
         assert ln.value == tl[i] and np.array_equal(row[1:-1], tight[i, :sb]), i
     assert L.cq_pack_read_tight(None, 5, 1, 25, None, None) == -1
     assert L.cq_pack_reads_tight(None, None, 0, 26, 0, None, None, None) == -1
+
+
+@pytest.mark.parametrize("isa", ["scalar", "bmi2"])
+def test_packers_agree_on_every_instruction_set(isa):
+    """The packer picks AVX2, BMI2 (PEXT) or the scalar table at run time; the tests above ran on the best one.
+    Run them again capped to the others (CAMMIQ_PACK_ISA is read once per process): all must give the rows the
+    independent Python packing expects."""
+    import subprocess
+    import sys
+    if os.environ.get("CAMMIQ_PACK_ISA_CHILD"):
+        pytest.skip("already inside the capped run")            # never recurse, whatever -k selects
+    env = dict(os.environ, CAMMIQ_PACK_ISA=isa, CAMMIQ_PACK_ISA_CHILD="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-p", "no:cacheprovider",
+                        "-k", "(test_packer or pack_read or tight_rows) and not instruction_set"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
