@@ -329,13 +329,30 @@ int prepare_host(const char *path_u, const char *path_d, double budget, std::sha
 // The image now lives in HBM: drop the host copy (cq_index_probe needs a CQ_DEVICE_NONE handle).
 void drop_host_image(HostIndex &H)
 {
-    H.img.table.reset();
-    std::vector<cq::Node>().swap(H.img.nodes);
-    std::vector<uint32_t>().swap(H.img.leaf_r1);
-    std::vector<uint32_t>().swap(H.img.leaf_r2);
+    // Giving several GB back to the OS takes hundreds of ms (0.4 s for configs[1]'s 3.2 GB table): a thread of its
+    // own does it while cq_index_load returns.
+    struct Dead { cq::HugeWords table; std::vector<cq::Node> nodes; std::vector<uint32_t> r1, r2; };
+    std::shared_ptr<Dead> d(new (std::nothrow) Dead());
+    if (!d) {   // no memory for the little carrier: free in place
+        H.img.table.reset();
+        std::vector<cq::Node>().swap(H.img.nodes);
+        std::vector<uint32_t>().swap(H.img.leaf_r1);
+        std::vector<uint32_t>().swap(H.img.leaf_r2);
+        return;
+    }
+    d->table = std::move(H.img.table);
+    d->nodes.swap(H.img.nodes);
+    d->r1.swap(H.img.leaf_r1);
+    d->r2.swap(H.img.leaf_r2);
+    try {
+        std::thread([d = std::move(d)]() mutable { d.reset(); }).detach();   // the thread holds the only reference
+    } catch (...) {
+        // could not start a thread: the closure died with the exception and freed everything here
+    }
 }
 
-void warm_workspace(cq_index *ix);   // below, next to the host-fed pipeline it prepares
+struct LoadTimer;
+void warm_workspace(cq_index *ix, LoadTimer *lt = nullptr);   // below, next to the host-fed pipeline it prepares
 
 double table_budget(int device)
 {
@@ -368,8 +385,9 @@ int cq_index_load(const char *path_u, const char *path_d, int device, cq_index *
         lt.lap("upload");
         if (rc != CQ_OK) { release_device(ix); delete ix; return rc; }
         drop_host_image(*ix->H);
-        warm_workspace(ix);
-        lt.lap("workspace");
+        lt.lap("release host image");
+        warm_workspace(ix, &lt);
+        lt.lap("workspace (rest)");
     }
     *out = ix;
     return CQ_OK;
@@ -603,22 +621,27 @@ int slot_reserve(cq_index::Slot &sl, uint64_t n, uint32_t sw, bool host_too)
 // hipMalloc / hipHostMalloc / stream and event creation for a 10 M-read FASTQ): streams, events, the two bounce
 // buffers, rcount, a counter block for up to 16 383 genomes, the slow-path list and the three device slots of one
 // 2 M-read chunk of 128-base rows.  Larger needs grow on demand as before.  Failures here are not errors.
-void warm_workspace(cq_index *ix)
+void warm_workspace(cq_index *ix, LoadTimer *lt)
 {
+    auto lap = [&](const char *w) { if (lt) lt->lap(w); };
     if (ix->device < 0 || hipSetDevice(ix->device) != hipSuccess) return;
     const cq::FlatImage &img = ix->H->img;
     if (!ix->s_copy) (void)hipStreamCreateWithFlags(&ix->s_copy, hipStreamNonBlocking);
     if (!ix->s_copy2) (void)hipStreamCreateWithFlags(&ix->s_copy2, hipStreamNonBlocking);
     if (!ix->s_comp) (void)hipStreamCreateWithFlags(&ix->s_comp, hipStreamNonBlocking);
+    lap("  streams");
     if (!ix->s_widen) (void)make_widen_stream(ix);
+    lap("  priority stream");
     for (auto &sl : ix->slot) {
         (void)slot_reserve(sl, kChunk, 8, false);
         if (!sl.d_tight && hipMalloc((void **)&sl.d_tight, kChunk * 32) == hipSuccess) sl.cap_tight = kChunk * 32;   // tight rows of up to 128 bases
     }
+    lap("  staging slots");
     for (int b = 0; b < 2; b++) {
         if (!ix->h_bounce[b] && hipHostMalloc(&ix->h_bounce[b], kBounce, hipHostMallocDefault) != hipSuccess) ix->h_bounce[b] = nullptr;
         if (!ix->ev_bounce[b]) (void)hipEventCreateWithFlags(&ix->ev_bounce[b], hipEventDisableTiming);
     }
+    lap("  bounce buffers");
     const uint64_t nl = img.n_leaves[0] + img.n_leaves[1], cw = cq_counter_words(16383);
     if (nl && !ix->d_rc && hipMalloc((void **)&ix->d_rc, nl * 4) == hipSuccess) ix->rc_cap = nl;
     if (!ix->d_ctr && hipMalloc((void **)&ix->d_ctr, cw * 8) == hipSuccess) ix->ctr_cap = cw;

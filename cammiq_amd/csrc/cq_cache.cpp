@@ -171,7 +171,7 @@ bool load_image(const std::string &file, const SourceStamp &src, double kpb_over
                 tab[t].leaves.resize(h.n_leaves[t]);
             }
             img = FlatImage();
-            img.table.reset(new uint32_t[h.table_words]);
+            img.table.alloc(h.table_words);
             img.table_words = h.table_words;
             img.nodes.resize(h.n_nodes);
         } catch (const std::bad_alloc &) { ok = false; }

@@ -34,6 +34,34 @@ struct DecodedTable {
     std::vector<Node> nodes;            // nodes[0] is a reserved dummy
 };
 
+// The table image on the host: an uninitialised uint32 array, first touched by all cores at once.  From 32 MB on it
+// is an anonymous mapping aligned to 2 MiB with MADV_HUGEPAGE -- where the host allows transparent huge pages the
+// layout's first touch takes 512 x fewer page faults, the upload pins fewer pages, and giving a multi-GB table back
+// is a few thousand pages instead of ~10^6 (0.35 s for configs[1]'s 3.2 GB, during which every other mmap of the
+// process waits).  Smaller tables come from the heap (and stay visible to the address sanitizer in the tests).
+class HugeWords {
+    void *base_ = nullptr;     // mapping (nullptr: heap)
+    size_t map_len_ = 0;
+    uint32_t *p_ = nullptr;
+
+public:
+    HugeWords() = default;
+    HugeWords(const HugeWords &) = delete;
+    HugeWords &operator=(const HugeWords &) = delete;
+    HugeWords(HugeWords &&o) noexcept : base_(o.base_), map_len_(o.map_len_), p_(o.p_) { o.base_ = nullptr; o.map_len_ = 0; o.p_ = nullptr; }
+    HugeWords &operator=(HugeWords &&o) noexcept
+    {
+        if (this != &o) { reset(); base_ = o.base_; map_len_ = o.map_len_; p_ = o.p_; o.base_ = nullptr; o.map_len_ = 0; o.p_ = nullptr; }
+        return *this;
+    }
+    ~HugeWords() { reset(); }
+    void alloc(size_t words);   // throws std::bad_alloc
+    void reset();
+    uint32_t *get() const { return p_; }
+    uint32_t &operator[](size_t i) const { return p_[i]; }
+    explicit operator bool() const { return p_ != nullptr; }
+};
+
 // Device-ready image.  Everything is plain arrays so upload is a handful of memcpys.
 struct FlatImage {
     uint32_t hash_len = 0;
@@ -46,7 +74,7 @@ struct FlatImage {
     uint32_t max_refid = 0;
     // CQ_BUCKET_WORDS words per bucket (layout in cq_device.h).  Not a std::vector: a multi-GB table
     // is allocated uninitialised and first touched by all cores at once.
-    std::unique_ptr<uint32_t[]> table;
+    HugeWords table;
     size_t table_words = 0;
     std::vector<Node> nodes;      // linked: d-table indices/leaf ids already offset
     std::vector<uint32_t> leaf_r1, leaf_r2;  // global leaf id -> refIDs (u leaves first)

@@ -32,7 +32,37 @@
 
 #include "cq_index.hpp"
 
+#include <sys/mman.h>
+#include <new>
+
 namespace cq {
+
+void HugeWords::alloc(size_t words)
+{
+    reset();
+    const size_t bytes = (words ? words : 1) * sizeof(uint32_t);
+    if (bytes < (32u << 20)) {
+        p_ = new uint32_t[words ? words : 1];
+        return;
+    }
+    const size_t two_mb = 2u << 20;
+    const size_t len = ((bytes + two_mb - 1) / two_mb + 1) * two_mb;   // room to align the start
+    void *m = mmap(nullptr, len, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+    if (m == MAP_FAILED) throw std::bad_alloc();
+    base_ = m;
+    map_len_ = len;
+    p_ = (uint32_t *)(((uintptr_t)m + two_mb - 1) / two_mb * two_mb);
+    (void)madvise(p_, (bytes + two_mb - 1) / two_mb * two_mb, MADV_HUGEPAGE);   // a hint: plain pages work too
+}
+
+void HugeWords::reset()
+{
+    if (base_) (void)munmap(base_, map_len_);
+    else delete[] p_;
+    base_ = nullptr;
+    map_len_ = 0;
+    p_ = nullptr;
+}
 
 namespace {
 
@@ -360,7 +390,7 @@ int build_image(const DecodedTable &u, const DecodedTable &d, double keys_per_bu
     //      redone until the carry has drained -- from there on the independent sweep was right.
     img.n_buckets_alloc = nbk + CQ_SPILL_TAIL;
     img.table_words = img.n_buckets_alloc * CQ_BUCKET_WORDS;
-    img.table.reset(new uint32_t[img.table_words]);   // uninitialised: the sweeps below first-touch it
+    img.table.alloc(img.table_words);   // uninitialised: the sweeps below first-touch it
     auto first_bucket = [&](unsigned p) -> uint64_t {   // smallest home with part_of(home) == p
         return p >= kParts ? img.n_buckets_alloc : ((uint64_t)p * nbk + kParts - 1) / kParts;
     };
@@ -438,7 +468,8 @@ int build_image(const DecodedTable &u, const DecodedTable &d, double keys_per_bu
         const uint64_t extra = (left.size() + CQ_SLOTS_PER_BUCKET - 1) / CQ_SLOTS_PER_BUCKET;
         const uint64_t old_alloc = img.n_buckets_alloc;
         if (old_alloc + extra >= 0xFFFFFFFFull) { err = "table would exceed 2^32 buckets"; return CQ_ERR_LIMIT; }
-        std::unique_ptr<uint32_t[]> grown(new uint32_t[(old_alloc + extra) * CQ_BUCKET_WORDS]);
+        HugeWords grown;
+        grown.alloc((old_alloc + extra) * CQ_BUCKET_WORDS);
         memcpy(grown.get(), img.table.get(), old_alloc * CQ_BUCKET_WORDS * sizeof(uint32_t));
         img.table = std::move(grown);
         img.n_buckets_alloc = old_alloc + extra;
