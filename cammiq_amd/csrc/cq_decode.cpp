@@ -140,6 +140,9 @@ int decode_table(const std::string &path, DecodedTable &out, std::string &err)
     out.leaves.reserve(guess);
     out.bucket_key.reserve(guess);
     out.bucket_code.reserve(guess);
+    advise_huge(out.leaves.data(), guess * sizeof(cq_leaf));        // one thread first-touches all of these
+    advise_huge(out.bucket_key.data(), guess * sizeof(uint64_t));
+    advise_huge(out.bucket_code.data(), guess * sizeof(uint32_t));
     out.nodes.push_back(Node{{0, 0, 0, 0}});  // index 0 reserved: code 0 means "absent"
 
     std::vector<Frame> stack;

@@ -37,6 +37,14 @@
 
 namespace cq {
 
+void advise_huge(const void *p, size_t bytes)
+{
+    const uintptr_t two_mb = 2u << 20;
+    if (!p || bytes < (32u << 20)) return;
+    const uintptr_t lo = ((uintptr_t)p + two_mb - 1) / two_mb * two_mb, hi = ((uintptr_t)p + bytes) / two_mb * two_mb;
+    if (hi > lo) (void)madvise((void *)lo, hi - lo, MADV_HUGEPAGE);   // whole 2 MiB frames inside the block; a hint only
+}
+
 void HugeWords::alloc(size_t words)
 {
     reset();
@@ -121,6 +129,7 @@ std::unique_ptr<Entry[]> sort_entries(std::unique_ptr<Entry[]> &e, size_t n, uin
     }
     part_begin[kParts] = run;
     std::unique_ptr<Entry[]> out(new Entry[n ? n : 1]);
+    advise_huge(out.get(), n * sizeof(Entry));
     Entry *tmp = out.get();
     parallel_for(nt, [&](unsigned t) {
         const size_t lo = n * t / nt, hi = n * (t + 1) / nt;
@@ -240,6 +249,10 @@ int build_image(const DecodedTable &u, const DecodedTable &d, double keys_per_bu
     img.nodes.clear();
     img.nodes.push_back(Node{{0, 0, 0, 0}});
 
+    img.leaf_r1.reserve(nu + nd);
+    img.leaf_r2.reserve(nu + nd);
+    advise_huge(img.leaf_r1.data(), (nu + nd) * sizeof(uint32_t));
+    advise_huge(img.leaf_r2.data(), (nu + nd) * sizeof(uint32_t));
     img.leaf_r1.resize(nu + nd);
     img.leaf_r2.resize(nu + nd);
     uint32_t maxr = 0;
@@ -272,6 +285,7 @@ int build_image(const DecodedTable &u, const DecodedTable &d, double keys_per_bu
     const uint32_t n_buckets = (uint32_t)nbk;
 
     std::unique_ptr<Entry[]> ent(new Entry[nb_u + nb_d ? nb_u + nb_d : 1]);   // uninitialised: filled (first touched) in parallel
+    advise_huge(ent.get(), (nb_u + nb_d) * sizeof(Entry));
     const size_t n_ent = nb_u + nb_d;
     // trie codes first: a bucket root that is a leaf (the usual case) is its own code; the others go
     // through path compression, which appends to one node array and therefore runs serially, in file order
