@@ -5,6 +5,13 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
+Both forms work for N > 1: called WITHOUT a launcher (no WORLD_SIZE in the environment) `--gpus N` starts its N
+ranks itself, as fresh child processes, before anything in this process has touched torch or the GPU, forwards
+rank 0's JSON line and exits with the ranks' status.  The control plane (the 128-byte communicator id, barriers,
+the max over ranks) is torch.distributed over **gloo**; the ONLY RCCL user in a rank is the product's own
+collective (cq_counts_allreduce in libcammiq_hip.so, /opt/rocm's librccl).  There is no fallback collective: a
+communicator that cannot be set up ends the run with a non-zero status.
+
 Workload at N = 1 = BASELINE.json configs[2] (the configuration north_star quotes the metric on):
 1000 synthetic bacterial-size genomes, --both index (unique + doubly-unique markers, h = k = 26),
 50 M x 100 bp reads per step.  `--config 1` runs configs[1] (500 genomes, --unique, 10 M reads).
@@ -81,6 +88,10 @@ def main():
                     help="skip the CPU oracle leg and its parity gate (used under rocprofv3 so that every "
                          "classify launch in the trace is a full-size timed step)")
     ap.add_argument("--no-host-fed", action="store_true", help="skip the PCIe-inclusive leg (cq_query_packed)")
+    ap.add_argument("--multi-leg", choices=["auto", "on", "off"], default="auto",
+                    help="N = 1 only: also run the same host-fed query through cq_multi_load / cq_multi_query_packed_tight (one "
+                         "process, one host thread per GPU, RCCL inside the library) on min(2, visible GPUs) devices and "
+                         "demand the single-device counts; auto = when at least two GPUs are visible")
     ap.add_argument("--ascii-api", action="store_true",
                     help="also time cq_query on ASCII reads in pageable memory (host packing included)")
     args = ap.parse_args()
@@ -92,13 +103,12 @@ def main():
                  and args.genome_len == 3_450_000)
     label = preset["label"] if is_preset else f"configs[{args.config}]-shape (modified)"
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args.gpus))      # nothing below has run yet: no torch import, no GPU touched
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N > 1 through torch.distributed.run (see the docstring)")
-        args.gpus = world
+    args.gpus = world
 
     import torch
     import cammiq_amd as cq
@@ -113,11 +123,10 @@ def main():
     dev = 0 if rehearsal else local_rank
     torch.cuda.set_device(dev)
     if world > 1:
+        # control plane only (id, barriers, max over ranks): gloo on the CPU.  torch's bundled RCCL is never brought
+        # up, so the product's collective is the one RCCL instance in the process.
         import torch.distributed as tdist
-        if rehearsal:
-            tdist.init_process_group("gloo")
-        else:
-            tdist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+        tdist.init_process_group("gloo")
 
     h = k = 26
     rl = args.read_len
@@ -144,8 +153,10 @@ def main():
         ix = cq.Index(pu, pd, device=dev)
         t_load = time.time() - t0
         info = ix.info_dict()
-        if local_rank == 0 and world == 1 and not (args.cpu_sample > 0 and not args.no_cpu_baseline):
-            shutil.rmtree(wdir, ignore_errors=True)    # the CPU leg is the only later reader of the files
+        n_vis = torch.cuda.device_count()
+        multi_leg = world == 1 and not args.no_host_fed and (args.multi_leg == "on" or (args.multi_leg == "auto" and n_vis >= 2))
+        if local_rank == 0 and world == 1 and not multi_leg and not (args.cpu_sample > 0 and not args.no_cpu_baseline):
+            shutil.rmtree(wdir, ignore_errors=True)    # the CPU leg and the multi leg are the only later readers of the files
 
         # ---- the batches: generated piecewise, packed once, resident in HBM (and, for the host-fed leg, in
         #      page-locked host memory).  Batch j of rank r is read stream 1000 + 16 r + j of the generator.
@@ -198,28 +209,19 @@ def main():
             if rehearsal:
                 reduce_how = "gloo (one-GPU rehearsal; not RCCL)"
             else:
-                try:
-                    uid = [cq.comm_unique_id() if rank == 0 else None]
-                    tdist.broadcast_object_list(uid, src=0)
-                    comm = cq.Comm(ix, uid[0], rank, world)
-                    # pre-flight: a 16-word block of ones must come back as 16 x world from the library's collective
-                    probe_t = torch.ones(16, dtype=torch.int64, device="cuda")
-                    probe_r = torch.ones(8, dtype=torch.int32, device="cuda")
-                    comm.allreduce_counts(probe_t.data_ptr(), 16, probe_r.data_ptr(), 8, stream)
-                    torch.cuda.synchronize()
-                    if int(probe_t.sum().item()) != 16 * world or int(probe_r.sum().item()) != 8 * world:
-                        raise RuntimeError("cq_counts_allreduce pre-flight returned a wrong sum")
-                    reduce_how = "cq_counts_allreduce (RCCL, libcammiq_hip.so)"
-                except Exception as e:   # keep the scaling run alive and say so in the record
-                    comm = None
-                    reduce_how = f"torch.distributed all_reduce (fallback: cq_comm failed: {e})"
-                    print(f"[bench rank {rank}] {reduce_how}", file=sys.stderr, flush=True)
-                flag = torch.tensor([1 if comm is not None else 0], device="cuda")
-                tdist.all_reduce(flag, op=tdist.ReduceOp.MIN)
-                if int(flag.item()) == 0 and comm is not None:   # all ranks take the same path
-                    comm.close()
-                    comm = None
-                    reduce_how = "torch.distributed all_reduce (fallback: cq_comm failed on another rank)"
+                # No fallback: if the product's communicator or its collective is broken the scaling run must say so
+                # (non-zero exit on every rank), not measure somebody else's all-reduce.
+                uid = [cq.comm_unique_id() if rank == 0 else None]
+                tdist.broadcast_object_list(uid, src=0)
+                comm = cq.Comm(ix, uid[0], rank, world)
+                # pre-flight: a 16-word block of ones must come back as 16 x world from the library's collective
+                probe_t = torch.ones(16, dtype=torch.int64, device="cuda")
+                probe_r = torch.ones(8, dtype=torch.int32, device="cuda")
+                comm.allreduce_counts(probe_t.data_ptr(), 16, probe_r.data_ptr(), 8, stream)
+                torch.cuda.synchronize()
+                if int(probe_t.sum().item()) != 16 * world or int(probe_r.sum().item()) != 8 * world:
+                    raise SystemExit(f"[bench rank {rank}] cq_counts_allreduce pre-flight returned a wrong sum")
+                reduce_how = "cq_counts_allreduce (RCCL in libcammiq_hip.so; control plane: gloo)"
 
         step_no = [0]
 
@@ -235,8 +237,11 @@ def main():
             if world > 1:
                 if comm is not None:
                     comm.allreduce_counts(ctr.data_ptr(), cw, rcd.data_ptr() if nleaf else None, nleaf, stream)
-                else:
-                    cqdist.allreduce_counts(ctr, rcd if nleaf else None)
+                else:                                                  # one-GPU rehearsal only: sum over gloo on the host
+                    torch.cuda.synchronize()
+                    hc, hr = ctr.cpu(), rcd.cpu()
+                    cqdist.allreduce_counts(hc, hr if nleaf else None)
+                    ctr.copy_(hc); rcd.copy_(hr)
             h_ctr.copy_(ctr, non_blocking=True)
             h_rc.copy_(rcd, non_blocking=True)                         # rcount once per query (pinned: link speed)
 
@@ -263,7 +268,7 @@ def main():
         fence()
         dt = time.perf_counter() - t0
         if world > 1:
-            tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
+            tmax = torch.tensor([dt], dtype=torch.float64)
             tdist.all_reduce(tmax, op=tdist.ReduceOp.MAX)
             dt = float(tmax.item())
 
@@ -291,9 +296,13 @@ def main():
             B = algorithmic_bytes_per_read(rl, h, 1)
             B_contract = algorithmic_bytes_per_read(rl, h, tables)
             achieved = n * B / (k_ms * 1e-3) / 1e9
+            li = ix.last_launch_info()
             roof = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                    "kernel": "classify_kernel<8,16,false>", "kernel_ms": round(k_ms, 4),
+                    "kernel": li["kernel"], "kernel_launch": {kk: li[kk] for kk in ("reads_per_subtile", "hit_slots", "lds_hist",
+                                                                                   "fixed_shape", "blocks_per_cu")},
+                    "kernel_ms": round(k_ms, 4), "kernel_ms_runs": [round(x, 4) for x in kms],
+                    "algorithmic_T": 1,
                     "slow_path_kernel_ms": round(k_slow_ms, 4),
                     "algorithmic_bytes_per_read": B,
                     "algorithmic_note": "ceil(rl/4) + 2*(rl-h+1)*16: one 16-B slot per window and strand; the merged "
@@ -301,24 +310,35 @@ def main():
                     "contract_T_tables_bytes_per_read": B_contract,
                     "contract_T_tables_GBs": round(n * B_contract / (k_ms * 1e-3) / 1e9, 2)}
             # measured HBM traffic + gather ceiling of this exact workload, from the committed PMC passes
-            tp = os.path.join(ROOT, "profiles", "traffic_r02.json")
             key = workload_key(G, args.genome_len, both, n, rl)
-            if os.path.exists(tp):
-                try:
-                    ent = json.load(open(tp)).get(key)
-                except Exception:
-                    ent = None
-                if ent:
-                    hb = float(ent["hbm_bytes_per_launch"])
-                    roof["traffic"] = hb
-                    roof["physical_GBs"] = round(hb / (k_ms * 1e-3) / 1e9, 2)
-                    roof["physical_frac"] = round(hb / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
-                    if ent.get("gather_ceiling_lines_per_s"):
-                        # 64-byte lines READ per second (FETCH_SIZE; writes left out) against the chip's measured rate of
-                        # random 16-byte loads from a table of this size
-                        lines = float(ent.get("fetch_bytes_per_launch", hb)) / 64.0 / (k_ms * 1e-3)
-                        roof["gather_ceiling_frac"] = round(lines / float(ent["gather_ceiling_lines_per_s"]), 5)
-                        roof["gather_ceiling_note"] = ent.get("gather_ceiling_note")
+            ent = None
+            for tp in ("traffic_r03.json", "traffic_r02.json"):   # the newest round that profiled this workload
+                tp = os.path.join(ROOT, "profiles", tp)
+                if ent is None and os.path.exists(tp):
+                    try:
+                        ent = json.load(open(tp)).get(key)
+                    except Exception:
+                        ent = None
+            if ent:
+                # the committed rocprofv3 --stats mean of this kernel on this workload (profiles/): the fraction a
+                # reader recomputing from profiles/ gets, next to the one measured live in this run
+                if ent.get("kernel_ms_rocprof_stats"):
+                    pm = float(ent["kernel_ms_rocprof_stats"])
+                    roof["profiled_kernel_ms"] = pm
+                    roof["frac_at_profiled_ms"] = round(n * B / (pm * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
+                    roof["profiled_source"] = ent.get("kernel_stats_file")
+                    if ent.get("in_kernel_clock_MHz"):
+                        roof["profiled_in_kernel_clock_MHz"] = ent["in_kernel_clock_MHz"]
+                hb = float(ent["hbm_bytes_per_launch"])
+                roof["traffic"] = hb
+                roof["physical_GBs"] = round(hb / (k_ms * 1e-3) / 1e9, 2)
+                roof["physical_frac"] = round(hb / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
+                if ent.get("gather_ceiling_lines_per_s"):
+                    # 64-byte lines READ per second (FETCH_SIZE; writes left out) against the chip's measured rate of
+                    # random 16-byte loads from a table of this size
+                    lines = float(ent.get("fetch_bytes_per_launch", hb)) / 64.0 / (k_ms * 1e-3)
+                    roof["gather_ceiling_frac"] = round(lines / float(ent["gather_ceiling_lines_per_s"]), 5)
+                    roof["gather_ceiling_note"] = ent.get("gather_ceiling_note")
             result = {
                 "metric": METRIC, "value": round(value, 3), "unit": "Mreads/s", "n_gpus": world,
                 "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
@@ -358,6 +378,9 @@ def main():
                 ts.append(time.perf_counter() - t0)
             th = min(ts)
             row_bytes = sb + 1
+            # SURVEY.md 8(d) defines the metric's bracket as H2D of packed reads + kernels + D2H: that number is this one
+            # (`value` is the task contract's HBM-resident rate); quote both whenever one is quoted
+            result["value_survey_8d_bracket"] = round(n / th / 1e6, 2)
             result["host_fed"] = {
                 "Mreads_s": round(n / th / 1e6, 2), "ms": round(th * 1e3, 3), "runs_ms": [round(x * 1e3, 3) for x in ts],
                 "rows_over_bracket_GBs": round(n * row_bytes / th / 1e9, 2), "bytes_per_read_on_the_wire": row_bytes,
@@ -377,6 +400,35 @@ def main():
             if nleaf:
                 assert np.array_equal(rcd.cpu().numpy().view(np.uint32)[:nu], hq["rcount_u"])
 
+        # ---- second N > 1 shape: ONE process, one host thread per GPU inside the library, the library's
+        #      own RCCL all-reduce -- the same host-fed query over min(2, visible GPUs) devices must give the counts
+        #      of the single-device query above.  A secondary leg: a failure is recorded in the line, never hidden.
+        if rank == 0 and multi_leg:
+            devs = list(range(min(2, n_vis)))
+            try:
+                t0 = time.perf_counter()
+                mm = cq.Multi(pu, pd, devs)
+                t_mload = time.perf_counter() - t0
+                mout = mm.shards[0].counts_out(G, pinned=True)
+                mm.query_packed_tight(h_packed[0][:1 << 16], h_lens[0][:1 << 16], rl, G, out=mout)
+                ts = []
+                for _ in range(2):
+                    t0 = time.perf_counter()
+                    mq = mm.query_packed_tight(h_packed[0], h_lens[0], rl, G, out=mout)
+                    ts.append(time.perf_counter() - t0)
+                same = all(np.array_equal(mq[kk], hq[kk]) for kk in ("cnt_u", "cnt_d", "rcount_u", "rcount_d")) \
+                    and mq["nundet"] == hq["nundet"] and mq["nconf"] == hq["nconf"]
+                result["multi_in_process"] = {
+                    "devices": devs, "Mreads_s": round(n / min(ts) / 1e6, 2), "ms": round(min(ts) * 1e3, 3),
+                    "equals_single_device": bool(same), "load_s": round(t_mload, 2),
+                    "what": "cq_multi_query_packed_tight: reads sharded over the devices by cq_shard_range, one host thread "
+                            "per device, ncclAllReduce of counter block + rcount inside libcammiq_hip.so, host takes device 0"}
+                mm.close()
+                if not same:
+                    raise SystemExit("multi-GPU (one process) counts differ from the single-device counts")
+            except cq.CammiqError as e:
+                result["multi_in_process"] = {"devices": devs, "error": str(e)}
+
         if rank == 0 and world == 1 and args.ascii_api and sample_bases is not None:
             so = np.arange(ns + 1, dtype=np.uint64) * np.uint64(rl)
             ix.query(sample_bases[:rl * 1000], so[:1001], G)
@@ -390,33 +442,48 @@ def main():
         if rank == 0 and world == 1 and not args.no_cpu_baseline and ns > 0:
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             import oracle_lib
-            cores = min(os.cpu_count() or 1, 16)   # a one-GPU box's CPU share is 16 cores
+            # all host cores this process may run on (the lease's share of the box; os.cpu_count() is the box)
+            try:
+                cores = len(os.sched_getaffinity(0))
+            except AttributeError:
+                cores = os.cpu_count() or 1
+            cores = max(1, min(cores, oracle_lib.lib().cqo_omp_max_threads() if not os.environ.get("OMP_NUM_THREADS") else cores))
             oi = oracle_lib.OracleIndex(pu, pd)
             sb, so = sample_bases, np.arange(ns + 1, dtype=np.uint64) * np.uint64(rl)
+            keys4 = ("cnt_u", "cnt_d", "rcount_u", "rcount_d")
             t0 = time.perf_counter()
-            ref = oi.query(sb, so, G, mode=0, nthreads=cores)
+            ref = oi.query(sb, so, G, mode=0, nthreads=cores, variant="critical")       # query64mt_p as written
             tc = time.perf_counter() - t0
             t0 = time.perf_counter()
-            fair = oi.query(sb, so, G, mode=0, nthreads=-cores)      # same work, atomic counters instead of the lock
+            tl = oi.query(sb, so, G, mode=0, nthreads=cores, variant="thread_local")    # SURVEY 8(d)'s optimised variant
+            tt = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            fair = oi.query(sb, so, G, mode=0, nthreads=cores, variant="atomic")        # same loop, atomics instead of the lock
             tf = time.perf_counter() - t0
-            assert all(np.array_equal(fair[kk], ref[kk]) for kk in ("cnt_u", "cnt_d", "rcount_u", "rcount_d"))
+            for other, nm in ((tl, "thread_local"), (fair, "atomic")):
+                assert all(np.array_equal(other[kk], ref[kk]) for kk in keys4) and other["nundet"] == ref["nundet"] \
+                    and other["nconf"] == ref["nconf"], f"CPU variant {nm} differs from the locked one"
             t0 = time.perf_counter()
             ns1 = max(ns // 8, 1)
             oi.query(sb[:ns1 * rl], so[:ns1 + 1], G, mode=0, nthreads=1)
             tc1 = time.perf_counter() - t0
             # parity gate on the very same sample, through the product's host API
             got = ix.query(sb, so, G)
-            parity = all(np.array_equal(got[kk], ref[kk]) for kk in ("cnt_u", "cnt_d", "rcount_u", "rcount_d")) \
+            parity = all(np.array_equal(got[kk], ref[kk]) for kk in keys4) \
                 and got["nundet"] == ref["nundet"] and got["nconf"] == ref["nconf"]
             if not parity:
                 raise SystemExit("PARITY FAILURE: GPU counters differ from the CPU oracle on the bench sample")
             result["cpu_baseline"] = {
                 "value": round(ns / tc / 1e6, 4), "unit": "Mreads/s", "cores": cores, "kind": "port",
-                "sample": f"first {ns} reads of batch 0, same index; OpenMP over reads with one global "
-                          f"critical section per update as query64mt_p (oracle/cammiq_oracle.c); "
-                          f"same sample with atomic counter updates instead of the lock ('fair' variant): "
-                          f"{ns / tf / 1e6:.4f} Mreads/s; single-thread rate on {ns1} reads: {ns1 / tc1 / 1e6:.4f} Mreads/s",
-                "cpu_model": _cpu_model(), "seconds": round(tc + tf + tc1, 2)}
+                "value_thread_local": round(ns / tt / 1e6, 4), "value_atomic": round(ns / tf / 1e6, 4),
+                "value_one_core": round(ns1 / tc1 / 1e6, 4),
+                "host_cores_online": os.cpu_count(),
+                "sample": f"first {ns} reads of batch 0, same index, {cores} OpenMP threads = every core this process may "
+                          f"use ({os.cpu_count()} online on the box). value: OpenMP over reads with one global critical "
+                          f"section per read as query64mt_p (oracle/cammiq_oracle.c); value_thread_local: per-thread "
+                          f"counters merged after the loop, rcount by atomics (SURVEY 8(d)'s optimised variant); "
+                          f"value_atomic: the locked loop with atomics instead; value_one_core: serial, {ns1} reads",
+                "cpu_model": _cpu_model(), "seconds": round(tc + tt + tf + tc1, 2)}
             result["parity_checked_reads"] = ns
         if rank == 0:
             print(json.dumps(result), flush=True)
@@ -429,6 +496,40 @@ def main():
             shutil.rmtree(wdir, ignore_errors=True)
         if world > 1:
             tdist.destroy_process_group()
+
+
+def self_launch(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks as fresh child processes (this process has
+    not imported torch or touched the GPU, and never will), rank 0 inherits stdout so its ONE JSON line is this
+    program's output; the other ranks' stdout goes to stderr.  Returns the exit status: 0 only if every rank
+    returned 0.  A rank that fails takes the others down (exact PIDs, no patterns)."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC is the only kind this host driver supports (RCCL)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    status = 0
+    alive = set(range(n))
+    while alive:
+        for r in sorted(alive):
+            rc = procs[r].poll()
+            if rc is None:
+                continue
+            alive.discard(r)
+            if rc != 0 and status == 0:
+                status = rc if rc > 0 else 1
+                print(f"[bench launcher] rank {r} exited with status {rc}: stopping the other ranks", file=sys.stderr, flush=True)
+                for q in alive:
+                    procs[q].terminate()
+        time.sleep(0.05)
+    return status
 
 
 def _cpu_model():

@@ -32,6 +32,12 @@ class _Info(C.Structure):
                 ("reserved_", C.c_uint32), ("device_bytes", C.c_uint64)]
 
 
+class _LaunchInfo(C.Structure):
+    _fields_ = [("reads_per_subtile", C.c_int32), ("hit_slots", C.c_int32), ("lds_hist", C.c_int32),
+                ("fixed_shape", C.c_int32), ("fixed_hash_len", C.c_int32), ("fixed_read_len", C.c_int32),
+                ("blocks_per_cu", C.c_int32), ("reserved", C.c_int32)]
+
+
 class _Counts(C.Structure):
     _fields_ = [("cnt_u", C.c_void_p), ("cnt_d", C.c_void_p), ("rcount_u", C.c_void_p),
                 ("rcount_d", C.c_void_p), ("nundet", C.c_uint64), ("nconf", C.c_uint64),
@@ -65,6 +71,7 @@ SIGNATURES = {
                                  C.POINTER(C.c_uint64)]),
     "cq_last_kernel_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "cq_last_kernel_times": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "cq_last_launch_info": (C.c_int, [C.c_void_p, C.POINTER(_LaunchInfo)]),
     "cq_query_packed": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32,
                                   C.c_uint32, C.c_uint32, C.POINTER(_Counts)]),
     "cq_pack_stride_bytes": (C.c_uint32, [C.c_uint32]),
@@ -303,6 +310,15 @@ class Index:
         a, b = C.c_float(0), C.c_float(0)
         _check(lib().cq_last_kernel_times(self._h, C.byref(a), C.byref(b)))
         return float(a.value), float(b.value)
+
+    def last_launch_info(self) -> dict:
+        """Which instantiation of the classify kernel the most recent launch ran (cq_last_launch_info)."""
+        li = _LaunchInfo()
+        _check(lib().cq_last_launch_info(self._h, C.byref(li)))
+        d = {k: int(getattr(li, k)) for k, _ in _LaunchInfo._fields_ if k != "reserved"}
+        fx = f",{d['fixed_hash_len']},{d['fixed_read_len']}" if d["fixed_shape"] else ",0,0"
+        d["kernel"] = f"classify_kernel<{d['reads_per_subtile']},{d['hit_slots']},false{fx}>"
+        return d
 
     def pairs_reserve(self, n_slots: int):
         _check(lib().cq_pairs_reserve(self._h, n_slots))

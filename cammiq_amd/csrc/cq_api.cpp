@@ -91,6 +91,7 @@ struct cq_index {
     uint32_t pair_cap = 0;          // slots, power of two
     hipEvent_t ev0 = nullptr, ev_mid = nullptr, ev1 = nullptr;   // start | fast kernel done | slow kernel done
     bool ev_valid = false;
+    cq::LaunchInfo last_launch{};   // what launch_classify chose for the most recent launch (cq_last_launch_info)
     // host-fed paths (cq_query, cq_query_packed): three staging slots so that packing chunk c+1 on
     // the CPU, its H2D copy and the classify kernel of chunk c overlap with slack for host jitter
     struct Slot {
@@ -140,6 +141,9 @@ void release_device(cq_index *ix)
                 if (FILE *fo = fopen(f, "w")) {
                     fprintf(fo, "staging %llu\nprepass %llu\nprobe %llu\nlookup %llu\ndecide %llu\n", (unsigned long long)v[0],
                             (unsigned long long)v[1], (unsigned long long)v[2], (unsigned long long)v[3], (unsigned long long)v[4]);
+                    // shader cycles / 100 MHz ticks over the waves' main loops: the clock the chip held under this kernel
+                    fprintf(fo, "shader_cycles %llu\nrealtime_ticks_100MHz %llu\nin_kernel_clock_MHz %.1f\n", (unsigned long long)v[5],
+                            (unsigned long long)v[6], v[6] ? 100.0 * (double)v[5] / (double)v[6] : 0.0);
                     fclose(fo);
                 }
         }
@@ -499,8 +503,24 @@ int cq_query_device(cq_index *ix, int mode, const uint32_t *d_packed, const uint
     a.pair_cnts = ix->d_pair_cnts;
     a.pair_cap = ix->pair_cap;
     a.stamps = ix->d_stamps;   // only written by diagnostic (CQ_STAMPS) builds
-    CQ_HIP(cq::launch_classify(ix->dev, a, ix->n_cus, st, ix->ev0, ix->ev_mid, ix->ev1));
+    CQ_HIP(cq::launch_classify(ix->dev, a, ix->n_cus, st, ix->ev0, ix->ev_mid, ix->ev1, &ix->last_launch));
     ix->ev_valid = true;
+    return CQ_OK;
+}
+
+int cq_last_launch_info(cq_index *ix, cq_launch_info *out)
+{
+    if (!ix || !out) return fail(CQ_ERR_ARG, "cq_last_launch_info: NULL argument");
+    if (!ix->ev_valid) return fail(CQ_ERR_ARG, "cq_last_launch_info: no kernel has been launched on this handle");
+    const cq::LaunchInfo &l = ix->last_launch;
+    out->reads_per_subtile = l.reads_per_subtile;
+    out->hit_slots = l.hit_slots;
+    out->lds_hist = l.lds_hist;
+    out->fixed_shape = l.fixed_shape;
+    out->fixed_hash_len = l.fixed_h;
+    out->fixed_read_len = l.fixed_read_len;
+    out->blocks_per_cu = l.blocks_per_cu;
+    out->reserved = 0;
     return CQ_OK;
 }
 
@@ -879,7 +899,14 @@ int fetch_counts(cq_index *ix, int mode, uint32_t n_genomes, cq_counts *out, uin
 int query_one(cq_index *ix, int mode, const Feed &f, uint64_t n_reads, uint32_t n_genomes, cq_counts *out)
 {
     for (;;) {
-        int rc = classify_range(ix, mode, f, 0, n_reads, n_genomes);
+        // "Counters are OVERWRITTEN": pairs an earlier query left behind (arrays too small, count-only fetch, a
+        // failure half-way) must not add onto this one.  They are kept for a second cq_pairs_fetch only until here.
+        int rc = CQ_OK;
+        if (mode == CQ_MODE_SC) {
+            CQ_HIP(hipSetDevice(ix->device));
+            if ((rc = pairs_clear(ix)) != CQ_OK) return rc;
+        }
+        rc = classify_range(ix, mode, f, 0, n_reads, n_genomes);
         if (rc != CQ_OK) return rc;
         uint64_t flags = 0;
         rc = fetch_counts(ix, mode, n_genomes, out, &flags);
@@ -894,6 +921,10 @@ int query_one(cq_index *ix, int mode, const Feed &f, uint64_t n_reads, uint32_t 
         uint64_t np = 0;
         rc = cq_pairs_fetch(ix, out->pair_a, out->pair_b, out->pair_cnt, out->pair_cap, &np);
         out->n_pairs = np;
+        // same contract as cq_multi_query: pairs that found no room in the caller's arrays are CQ_ERR_LIMIT with
+        // n_pairs = the number needed (the map is kept for a cq_pairs_fetch with larger arrays until the next query)
+        if (rc == CQ_OK && np && !(out->pair_a && out->pair_b && out->pair_cnt))
+            return fail(CQ_ERR_LIMIT, "more distinct pairs than pair_cap (no pair arrays given: call cq_pairs_fetch with arrays of n_pairs entries)");
         return rc;
     }
 }
@@ -1115,6 +1146,12 @@ int multi_query(cq_multi *m, int mode, const Feed &f, uint64_t n_reads, uint32_t
     const uint64_t nl = img.n_leaves[0] + img.n_leaves[1];
     const bool rc_on = mode == CQ_MODE_P && nl;
     for (;;) {
+        if (mode == CQ_MODE_SC)   // as query_one: nothing an earlier query left in a shard's pair map may add onto this one
+            for (int p = 0; p < P; p++) {
+                CQ_HIP(hipSetDevice(m->ix[p]->device));
+                int rc = pairs_clear(m->ix[p]);
+                if (rc != CQ_OK) return rc;
+            }
         // ---- shard p classifies reads [n*p/P, n*(p+1)/P) on its device (the loop of query.cpp:664-665)
         std::vector<int> rcs(P, CQ_OK);
         std::vector<std::string> errs(P);

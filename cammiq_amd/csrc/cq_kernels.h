@@ -46,9 +46,19 @@ struct QueryArgs {
     uint64_t *stamps;        // diagnostic builds only (CQ_STAMPS): per-phase cycle sums, else null
 };
 
-// ev_start | fast kernel | ev_mid | exact slow-path kernel | ev_stop  (events may be null)
+// What launch_classify chose for a launch (cq_last_launch_info): the fast kernel's instantiation.
+struct LaunchInfo {
+    int reads_per_subtile = 0;   // R: 8, or 4 for long reads
+    int hit_slots = 0;           // CAP of the fast kernel
+    int lds_hist = 0;            // per-genome counters in an LDS histogram (1) or as global atomics (0)
+    int fixed_shape = 0;         // 1: the instantiation with hash length and batch shape as compile-time constants
+    int fixed_h = 0, fixed_read_len = 0;
+    int blocks_per_cu = 0;       // resident workgroups per CU the persistent grid was sized for
+};
+
+// ev_start | fast kernel | ev_mid | exact slow-path kernel | ev_stop  (events may be null; info may be null)
 hipError_t launch_classify(const DevIndex &ix, QueryArgs a, int n_cus, hipStream_t stream,
-                           hipEvent_t ev_start, hipEvent_t ev_mid, hipEvent_t ev_stop);
+                           hipEvent_t ev_start, hipEvent_t ev_mid, hipEvent_t ev_stop, LaunchInfo *info = nullptr);
 
 // dst += src, element-wise, for a counter block (uint64) and an rcount array (uint32; may be null):
 // sums shards that ran on the SAME device (cq_multi rehearsal); distinct devices meet in RCCL.

@@ -38,6 +38,9 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <mutex>
+#include <vector>
+
 #include "cq_device.h"
 #include "cq_kernels.h"
 
@@ -204,10 +207,9 @@ __device__ __forceinline__ uint64_t row_bits64(const uint32_t *row, int off)
 // query.cpp:447-450).  A chain node stands for `len` single-child inner nodes: the walk
 // either matches all of its symbols or ends without a leaf, exactly like the symbol-by-symbol
 // loop (inner nodes are never leaves; running out of read inside the chain returns NULL).
-__device__ __forceinline__ uint32_t walk_trie(const DevIndex &ix, const uint32_t *row, uint32_t len,
+__device__ __forceinline__ uint32_t walk_trie(const DevIndex &ix, uint32_t h, const uint32_t *row, uint32_t len,
                                               uint32_t code, uint32_t strand, uint32_t p)
 {
-    const uint32_t h = ix.hash_len;
     const uint32_t rem = strand ? p : (len - h - p);
     uint32_t j = 0;
     for (;;) {
@@ -262,10 +264,10 @@ __device__ __forceinline__ void append_hit(const Tile &t, uint32_t rl, uint32_t 
 // Resolve one candidate: walk the trie below the bucket root (most codes are depth-0 leaves
 // already), fetch the leaf's refIDs, append to the read's hit list.
 template <int CAP>
-__device__ __forceinline__ void resolve(const DevIndex &ix, const Tile &t, const uint32_t *row, uint32_t len,
+__device__ __forceinline__ void resolve(const DevIndex &ix, uint32_t h, const Tile &t, const uint32_t *row, uint32_t len,
                                         uint32_t rl, uint32_t code, uint32_t strand, uint32_t p)
 {
-    const uint32_t gid = walk_trie(ix, row, len, code, strand, p);
+    const uint32_t gid = walk_trie(ix, h, row, len, code, strand, p);
     if (gid != 0xFFFFFFFFu) {
         const uint2 rr = ix.leaf_rids[gid];
         append_hit<CAP>(t, rl, gid, rr.x, rr.y);
@@ -275,7 +277,7 @@ __device__ __forceinline__ void resolve(const DevIndex &ix, const Tile &t, const
 // A slot's (val_u, val_d) pair for one strand.  The common case -- a unique marker of length
 // h, nothing in ht_d -- has the leaf's refID inline in val_d: no trie walk, no leaf_rids read.
 template <int CAP>
-__device__ __forceinline__ void resolve_pair(const DevIndex &ix, const Tile &t, const uint32_t *row, uint32_t len,
+__device__ __forceinline__ void resolve_pair(const DevIndex &ix, uint32_t h, const Tile &t, const uint32_t *row, uint32_t len,
                                              uint32_t rl, uint2 v, uint32_t strand, uint32_t p)
 {
     if ((v.y >> 30) == 1u) {                                       // CQ_INLINE_RID_BIT
@@ -286,24 +288,23 @@ __device__ __forceinline__ void resolve_pair(const DevIndex &ix, const Tile &t, 
         append_hit<CAP>(t, rl, v.y & ~CQ_LEAF_BIT, (v.x >> 15) & 0x7FFFu, v.x & 0x7FFFu);
         return;
     }
-    if (v.x) resolve<CAP>(ix, t, row, len, rl, v.x, strand, p);   // ht_u
-    if (v.y) resolve<CAP>(ix, t, row, len, rl, v.y, strand, p);   // ht_d
+    if (v.x) resolve<CAP>(ix, h, t, row, len, rl, v.x, strand, p);   // ht_u
+    if (v.y) resolve<CAP>(ix, h, t, row, len, rl, v.y, strand, p);   // ht_d
 }
 
 // The exact lookup of one window (both strands): full 64-bit key compare along the bucket
 // chain, then trie walk + hit append for every table that holds the h-mer.  Runs only for
 // the few windows the probe loop flagged, one window per lane, all lanes busy.
 template <int CAP>
-__device__ __forceinline__ void lookup_window(const DevIndex &ix, const Tile &t, uint32_t swp, uint32_t pstride, uint32_t rl,
-                                              uint32_t pw, uint32_t b)
+__device__ __forceinline__ void lookup_window(const DevIndex &ix, uint32_t h, uint32_t m, const Tile &t, uint32_t swp,
+                                              uint32_t pstride, uint32_t rl, uint32_t pw, uint32_t b)
 {
-    const uint32_t h = ix.hash_len;
     const uint32_t *row = t.rows + rl * swp;
     const uint32_t len = t.len[rl];
     if (b == kNoBucket) {   // the probe loop kept no bucket for this window (fourth minimizer of its lane): look it up again
         const uint32_t *ph = t.phi + rl * pstride + pw;
         uint32_t v = ph[0];
-        for (uint32_t i = 1; i + ix.minimizer_len <= h; i++) v = min(v, ph[i]);
+        for (uint32_t i = 1; i + m <= h; i++) v = min(v, ph[i]);
         b = cq_bucket_of_minimizer(v, ix.n_buckets);
     }
     // forward h-mer = bit-field of the row; reverse complement = ~bitreverse
@@ -319,18 +320,19 @@ __device__ __forceinline__ void lookup_window(const DevIndex &ix, const Tile &t,
         more = match_bucket(bk, fw, rc, vf, vr, ff, fr);
     } while (more && CQ_EXP != 2 && CQ_EXP != 4);
     if (CQ_EXP == 4) return;
-    if (vf.x | vf.y) resolve_pair<CAP>(ix, t, row, len, rl, vf, 0, pw);   // forward strand
-    if (vr.x | vr.y) resolve_pair<CAP>(ix, t, row, len, rl, vr, 1, pw);   // reverse strand
+    if (vf.x | vf.y) resolve_pair<CAP>(ix, h, t, row, len, rl, vf, 0, pw);   // forward strand
+    if (vr.x | vr.y) resolve_pair<CAP>(ix, h, t, row, len, rl, vr, 1, pw);   // reverse strand
 }
 
 // Drain this wave's work list (n <= kWorkCap items: .x = bucket, .y = read | window << 8).
 template <int CAP>
-__device__ __forceinline__ void drain_work(const DevIndex &ix, const Tile &t, uint32_t swp, uint32_t pstride, uint32_t n)
+__device__ __forceinline__ void drain_work(const DevIndex &ix, uint32_t h, uint32_t m, const Tile &t, uint32_t swp,
+                                           uint32_t pstride, uint32_t n)
 {
     wave_sync();
     for (uint32_t i = lane_id(); i < n; i += 64) {
         const uint2 it = t.work[i];
-        lookup_window<CAP>(ix, t, swp, pstride, it.y & 255u, it.y >> 8, it.x);
+        lookup_window<CAP>(ix, h, m, t, swp, pstride, it.y & 255u, it.y >> 8, it.x);
     }
     wave_sync();
 }
@@ -432,16 +434,30 @@ __device__ __forceinline__ void decide(const QueryArgs &a, const Tile &t, uint32
 #ifndef CQ_WAVES_PER_EU
 #define CQ_WAVES_PER_EU 6   /* register budget: 512 / 6 -> 80 VGPRs */
 #endif
-template <int R, int CAP, bool SLOW>
+//
+// H, RL: 0 = hash length and batch shape are launch arguments (any index, any read length).  H = 26, RL = 100 / 150
+// is the SAME code with CAMMiQ's default hash length (main.cpp:335-346) and the benchmark read lengths folded in as
+// constants: the row stride, the windows / m-mer positions per read, the four small-division magics, every 2h shift
+// and the minimizer network's shape stop being SGPR-resident launch arguments.  Chosen by launch_classify when index
+// and batch match; results are those of the generic instantiation (tests/test_gpu_parity.py runs both).
+constexpr uint32_t magic_of_c(uint32_t d) { return d == 0 ? 0u : (uint32_t)(((1u << 19) + d - 1) / d); }
+template <int R, int CAP, bool SLOW, int H, int RL>
 __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(CQ_WAVES_PER_EU, CQ_WAVES_PER_EU)))
 classify_kernel(DevIndex ix, QueryArgs a)
 {
     static_assert(SLOW || R * 4 <= 64, "a sub-tile's rows (R x <= 16 words) must fit one 16-byte load per lane");
+    static_assert((H == 0) == (RL == 0) && (H == 0 || (H >= 5 && H <= 31 && RL >= H && RL <= 255)), "H and RL are fixed together");
+    constexpr bool FX = H != 0;
+    constexpr uint32_t cM = H < CQ_MAX_MINIMIZER ? H : CQ_MAX_MINIMIZER, cW = FX ? RL - H + 1 : 0, cP = cW + (H - cM);
     extern __shared__ __align__(16) uint32_t smem[];
-    const uint32_t sw = a.stride_words, swp = sw | 1u;
+    const uint32_t sw = FX ? (uint32_t)(RL + 15) / 16 : a.stride_words, swp = sw | 1u;
     const uint32_t G1 = a.n_genomes + 1;
-    const uint32_t h = ix.hash_len, m = ix.minimizer_len, nphi = h - m + 1;
-    const uint32_t wmax = a.wmax, pmax = a.pmax, pstride = a.pstride;
+    const uint32_t h = FX ? (uint32_t)H : ix.hash_len, m = FX ? cM : ix.minimizer_len, nphi = h - m + 1;
+    const uint32_t wmax = FX ? cW : a.wmax, pmax = FX ? cP : a.pmax;
+    const uint32_t pstride = FX ? (((cP + kPrePos - 1u) / kPrePos * kPrePos) | 1u) : a.pstride;
+    const uint32_t magic_s = FX ? magic_of_c((RL + 15) / 16) : a.magic_s;
+    const uint32_t magic_pp = FX ? magic_of_c((cP + kPrePos - 1u) / kPrePos) : a.magic_pp;
+    const uint32_t magic_w = FX ? magic_of_c((cW + kWinPerLane - 1u) / kWinPerLane) : a.magic_w;
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
     const SmemLayout L = smem_layout(R, CAP, sw, pstride, a.n_genomes, a.use_lds_hist != 0);
     uint32_t *mine = smem + wave * L.per_wave;
@@ -497,6 +513,9 @@ classify_kernel(DevIndex ix, QueryArgs a)
 #if CQ_STAMPS
     unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0}, st_last;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last) :: "memory");
+    // in-kernel clock (MI355X_MICROARCH.md, DVFS item 6): shader cycles (s_memtime) over the 100 MHz constant
+    // clock (s_memrealtime) across this wave's whole main loop
+    const unsigned long long ck_c0 = st_last, ck_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
     for (uint64_t sub = wave_gid; sub < n_sub; sub += n_waves) {
         const uint64_t r0 = sub * R;
@@ -516,7 +535,7 @@ classify_kernel(DevIndex ix, QueryArgs a)
                     asm volatile("" : "+v"(wv));   // not loop-invariant for the compiler: four hoisted addresses would cost registers on the odd-stride path
 #pragma unroll
                     for (uint32_t i = 0; i < 4; i++)
-                        if (wv + i < nwords) t.rows[wv + i + div_small(wv + i, sw, a.magic_s)] = v[i];
+                        if (wv + i < nwords) t.rows[wv + i + div_small(wv + i, sw, magic_s)] = v[i];
                 }
             }
         } else {
@@ -543,7 +562,7 @@ classify_kernel(DevIndex ix, QueryArgs a)
             const uint32_t total = nr * gpr;
             const uint32_t mmask = m >= 16 ? 0xFFFFFFFFu : (1u << (2u * m)) - 1u;
             for (uint32_t it = lane; it < (CQ_EXP == 10 ? 0u : total); it += 64) {
-                const uint32_t rl = div_small(it, gpr, a.magic_pp), j = (it - __umul24(rl, gpr)) * kPrePos;
+                const uint32_t rl = div_small(it, gpr, magic_pp), j = (it - __umul24(rl, gpr)) * kPrePos;
                 const uint32_t len = t.len[rl];
                 if (j + m > len) continue;
                 const uint32_t *row = t.rows + __umul24(rl, swp);
@@ -593,7 +612,7 @@ classify_kernel(DevIndex ix, QueryArgs a)
 #pragma unroll
             for (uint32_t r = 0; r < NS; r++) bkt[r] = 0;
             if (act) {
-                rl = div_small(idx, gpr, a.magic_w);
+                rl = div_small(idx, gpr, magic_w);
                 pw0 = (idx - __umul24(rl, gpr)) * KW;
                 len = t.len[rl];
                 act = (len >= h) && (pw0 + h <= len);
@@ -724,11 +743,11 @@ classify_kernel(DevIndex ix, QueryArgs a)
                     t.work[off] = make_uint2(b, rl | ((pw0 + k) << 8));
                 }
                 nw += (uint32_t)__popcll(mask);
-                if (nw >= (uint32_t)kWorkDrain) { CQ_STAMP(2); if (CQ_EXP != 1) drain_work<CAP>(ix, t, swp, pstride, nw); nw = 0; CQ_STAMP(3); }
+                if (nw >= (uint32_t)kWorkDrain) { CQ_STAMP(2); if (CQ_EXP != 1) drain_work<CAP>(ix, h, m, t, swp, pstride, nw); nw = 0; CQ_STAMP(3); }
             }
         }
         CQ_STAMP(2);   // probe loop
-        if (nw && CQ_EXP != 1) drain_work<CAP>(ix, t, swp, pstride, nw);
+        if (nw && CQ_EXP != 1) drain_work<CAP>(ix, h, m, t, swp, pstride, nw);
         CQ_STAMP(3);   // exact lookups
         wave_sync();
 
@@ -751,8 +770,12 @@ classify_kernel(DevIndex ix, QueryArgs a)
         CQ_STAMP(4);   // decision
     }
 #if CQ_STAMPS
-    if (!SLOW && lane == 0 && a.stamps)
+    if (!SLOW && lane == 0 && a.stamps) {
         for (int i = 0; i < 5; i++) atomicAdd((unsigned long long *)&a.stamps[i], st_acc[i]);
+        const unsigned long long ck_r1 = __builtin_amdgcn_s_memrealtime();
+        atomicAdd((unsigned long long *)&a.stamps[5], st_last - ck_c0);   // st_last = the last phase stamp of this wave
+        atomicAdd((unsigned long long *)&a.stamps[6], ck_r1 - ck_r0);
+    }
 #endif
 
     // ---- flush workgroup-level counters
@@ -843,28 +866,69 @@ hipError_t launch_accumulate(uint64_t *dst64, const uint64_t *src64, uint64_t n6
 
 namespace {
 
-template <int R>
-hipError_t fast_resident(const QueryArgs &a, bool hist, int &n)
+// ---- what is launched -----------------------------------------------------------------------------------------
+// One fast-kernel instantiation = (reads per sub-tile, fixed shape).  The occupancy questions behind the choice
+// cost HIP runtime calls (hipFuncSetAttribute + hipOccupancyMaxActiveBlocksPerMultiprocessor: tens of
+// microseconds, 24 x per host-fed query when asked per chunk), so their answers are kept per (device, variant,
+// LDS bytes): the first launch of a shape pays, later launches look up.
+enum Variant { kV8 = 0, kV4 = 1, kV8h26r100 = 2, kV8h26r150 = 3, kVSlow = 4, kNVariants = 5 };
+
+const void *variant_fn(int v)
 {
-    // LDS above the 64 KiB default needs an explicit opt-in (large G)
-    hipError_t e = hipFuncSetAttribute((const void *)classify_kernel<R, kFastCAP, false>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    switch (v) {
+    case kV8: return (const void *)classify_kernel<8, kFastCAP, false, 0, 0>;
+    case kV4: return (const void *)classify_kernel<4, kFastCAP, false, 0, 0>;
+    case kV8h26r100: return (const void *)classify_kernel<8, kFastCAP, false, 26, 100>;
+    case kV8h26r150: return (const void *)classify_kernel<8, kFastCAP, false, 26, 150>;
+    default: return (const void *)classify_kernel<kSlowR, kSlowCAP, true, 0, 0>;
+    }
+}
+
+struct OccKey { int dev, variant; size_t smem; };
+struct OccEnt { OccKey k; int blocks; };
+std::mutex g_occ_mu;
+std::vector<OccEnt> g_occ;
+bool g_attr_done[64][kNVariants];   // hipFuncSetAttribute(160 KB of LDS) once per device and kernel
+
+hipError_t ensure_lds_optin(int dev, int v)
+{
+    if (dev >= 0 && dev < 64 && g_attr_done[dev][v]) return hipSuccess;
+    // LDS above the 64 KiB default needs an explicit opt-in (large G, long reads, the slow path's hit lists)
+    hipError_t e = hipFuncSetAttribute(variant_fn(v), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess && dev >= 0 && dev < 64) g_attr_done[dev][v] = true;
+    return e;
+}
+
+// Resident workgroups per CU of a fast variant with `sm` bytes of LDS.
+hipError_t fast_resident(int dev, int v, size_t sm, int &n)
+{
+    std::lock_guard<std::mutex> lk(g_occ_mu);
+    for (const OccEnt &e : g_occ)
+        if (e.k.dev == dev && e.k.variant == v && e.k.smem == sm) { n = e.blocks; return hipSuccess; }
+    hipError_t e = ensure_lds_optin(dev, v);
     if (e != hipSuccess) return e;
-    const size_t sm = smem_bytes(R, kFastCAP, a, hist);
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)classify_kernel<R, kFastCAP, false>, kBlock, sm);
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, variant_fn(v), kBlock, sm);
+    if (e != hipSuccess) return e;
     // The 160 KB are handed out in 1280-byte granules (measured: 5 x 32292 B = 161460 B fit by arithmetic and by the
     // occupancy query, yet only four such workgroups were resident; 5 x 31524 B were): a sub-tile or a histogram
     // that just fits can still cost a workgroup, so count in granules.
     const int by_granules = (int)((160u * 1024u) / ((sm + 1279u) / 1280u * 1280u));
     if (n > by_granules) n = by_granules;
     if (n > CQ_MAX_BLOCKS_PER_CU) n = CQ_MAX_BLOCKS_PER_CU;
-    return e;
+    g_occ.push_back(OccEnt{OccKey{dev, v, sm}, n});
+    return hipSuccess;
+}
+
+template <int R, int H, int RL>
+void launch_one(const DevIndex &ix, const QueryArgs &a, unsigned grid, size_t sm, hipStream_t stream)
+{
+    hipLaunchKernelGGL((classify_kernel<R, kFastCAP, false, H, RL>), dim3(grid), dim3(kBlock), sm, stream, ix, a);
 }
 
 // The fast kernel: persistent waves, each walking its own sub-tiles of R reads.
-template <int R>
-hipError_t launch_fast(const DevIndex &ix, QueryArgs &a, int n_cus, int per_cu, hipStream_t stream)
+hipError_t launch_fast(int variant, const DevIndex &ix, QueryArgs &a, int n_cus, int per_cu, hipStream_t stream)
 {
+    const int R = variant == kV4 ? 4 : 8;
     const size_t sm = smem_bytes(R, kFastCAP, a, a.use_lds_hist);
     if (const char *v = getenv("CAMMIQ_BLOCKS_PER_CU")) per_cu = atoi(v);   // tuning knob
     if (per_cu < 1) per_cu = 1;
@@ -873,7 +937,7 @@ hipError_t launch_fast(const DevIndex &ix, QueryArgs &a, int n_cus, int per_cu, 
     // 1 to a genome's cnt_u and at most 2 to its cnt_d (a pair (g, g)), so a workgroup must not classify more than
     // 32767 reads per launch: a wave takes at most max_sub sub-tiles, longer inputs are cut into several
     // launches (configs[2]'s 50 M reads per launch still fit one: 1536 workgroups x 32736 reads).
-    uint64_t max_sub = kMaxReadsPerGroup / (kWaves * R);
+    uint64_t max_sub = kMaxReadsPerGroup / (uint64_t)(kWaves * R);
     if (const char *v = getenv("CAMMIQ_MAX_SUB_PER_WAVE")) max_sub = (uint64_t)atoi(v) >= 1 && (uint64_t)atoi(v) < max_sub ? (uint64_t)atoi(v) : max_sub;   // test knob
     const uint64_t chunk = a.use_lds_hist ? grid_full * kWaves * max_sub * R : a.n_reads;
     const uint32_t *packed0 = a.packed;
@@ -890,7 +954,12 @@ hipError_t launch_fast(const DevIndex &ix, QueryArgs &a, int n_cus, int per_cu, 
         const uint64_t need = (n_sub + kWaves - 1) / kWaves;
         if (grid > need) grid = need;
         if (grid == 0) grid = 1;
-        hipLaunchKernelGGL((classify_kernel<R, kFastCAP, false>), dim3((unsigned)grid), dim3(kBlock), sm, stream, ix, a);
+        switch (variant) {
+        case kV4: launch_one<4, 0, 0>(ix, a, (unsigned)grid, sm, stream); break;
+        case kV8h26r100: launch_one<8, 26, 100>(ix, a, (unsigned)grid, sm, stream); break;
+        case kV8h26r150: launch_one<8, 26, 150>(ix, a, (unsigned)grid, sm, stream); break;
+        default: launch_one<8, 0, 0>(ix, a, (unsigned)grid, sm, stream); break;
+        }
         e = hipGetLastError();
         if (e != hipSuccess) break;
     }
@@ -901,7 +970,7 @@ hipError_t launch_fast(const DevIndex &ix, QueryArgs &a, int n_cus, int per_cu, 
 }  // namespace
 
 hipError_t launch_classify(const DevIndex &ix, QueryArgs a, int n_cus, hipStream_t stream,
-                           hipEvent_t ev_start, hipEvent_t ev_mid, hipEvent_t ev_stop)
+                           hipEvent_t ev_start, hipEvent_t ev_mid, hipEvent_t ev_stop, LaunchInfo *info)
 {
     a.pmax = a.wmax + (ix.hash_len - ix.minimizer_len);   // m-mer positions: max_len - m + 1
     a.pstride = ((a.pmax + kPrePos - 1u) / kPrePos * kPrePos) | 1u;   // whole position groups (the pre-pass stores unconditionally), odd (banks)
@@ -909,25 +978,44 @@ hipError_t launch_classify(const DevIndex &ix, QueryArgs a, int n_cus, hipStream
     a.magic_p = magic_of(a.pmax);
     a.magic_s = magic_of(a.stride_words);
     a.magic_pp = magic_of((a.pmax + kPrePos - 1u) / kPrePos);
-    hipError_t e = hipFuncSetAttribute((const void *)classify_kernel<kSlowR, kSlowCAP, true>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
-    // Two choices per launch, both by what stays resident (six workgroups per CU is what the registers allow):
+    if ((e = ensure_lds_optin(dev, kVSlow)) != hipSuccess) return e;
+    // Three choices per launch, the first two by what stays resident (six workgroups per CU is what the registers allow):
     //  * reads per sub-tile: eight, unless eight leave three workgroups or fewer and four keep more (rows and hash
     //    words of long reads);
     //  * per-genome counters: an LDS histogram per workgroup when it costs no resident workgroup, global 64-bit
-    //    atomics otherwise -- measured: the atomics cost 4 %, a lost workgroup 8 %.
+    //    atomics otherwise -- measured: the atomics cost 4 %, a lost workgroup 8 %;
+    //  * the instantiation with h = 26 and the batch's shape folded in, when index and batch are that shape.
     const bool hist_ok = lds_hist_fits(a.n_genomes), hist_forced = getenv("CAMMIQ_LDS_HIST_MAX") != nullptr;
     int r8 = 0, r4 = 0, r8h = 0, r4h = 0;
-    if ((e = fast_resident<8>(a, false, r8)) != hipSuccess || (e = fast_resident<4>(a, false, r4)) != hipSuccess) return e;
-    if (hist_ok && ((e = fast_resident<8>(a, true, r8h)) != hipSuccess || (e = fast_resident<4>(a, true, r4h)) != hipSuccess)) return e;
+    if ((e = fast_resident(dev, kV8, smem_bytes(8, kFastCAP, a, false), r8)) != hipSuccess ||
+        (e = fast_resident(dev, kV4, smem_bytes(4, kFastCAP, a, false), r4)) != hipSuccess) return e;
+    if (hist_ok && ((e = fast_resident(dev, kV8, smem_bytes(8, kFastCAP, a, true), r8h)) != hipSuccess ||
+                    (e = fast_resident(dev, kV4, smem_bytes(4, kFastCAP, a, true), r4h)) != hipSuccess)) return e;
     int R = (r8 <= 3 && r4 > r8) ? 4 : 8;   // measured: four reads per sub-tile cost 14 % at equal residency and 8 % at 6 against 5 workgroups (150 bp), and win 13 % at 6 against 3 (250 bp)
     if (const char *v = getenv("CAMMIQ_FAST_R")) R = atoi(v) == 4 ? 4 : 8;   // tuning knob
     const int plain = R == 8 ? r8 : r4, with = R == 8 ? r8h : r4h;
     a.use_lds_hist = hist_ok && (hist_forced || with >= plain) ? 1 : 0;
-    const int per_cu = a.use_lds_hist ? with : plain;
+    int per_cu = a.use_lds_hist ? with : plain;
+    int variant = R == 4 ? kV4 : kV8;
+    const char *nofix = getenv("CAMMIQ_NO_FIXED_SHAPE");   // test / A-B knob: always the generic instantiation
+    if (R == 8 && ix.hash_len == 26 && !(nofix && atoi(nofix))) {
+        int fx = -1;
+        if (a.wmax == 100 - 26 + 1 && a.stride_words == 7) fx = kV8h26r100;
+        if (a.wmax == 150 - 26 + 1 && a.stride_words == 10) fx = kV8h26r150;
+        if (fx >= 0) {
+            int n = 0;   // same LDS layout as the generic kernel of this shape; its own register count
+            if ((e = fast_resident(dev, fx, smem_bytes(8, kFastCAP, a, a.use_lds_hist != 0), n)) != hipSuccess) return e;
+            if (n >= per_cu) { variant = fx; per_cu = n; }
+        }
+    }
+    if (info) { info->reads_per_subtile = R; info->hit_slots = kFastCAP; info->lds_hist = (int)a.use_lds_hist; info->fixed_shape = variant >= kV8h26r100 ? 1 : 0;
+                info->fixed_h = variant >= kV8h26r100 ? 26 : 0; info->fixed_read_len = variant == kV8h26r100 ? 100 : variant == kV8h26r150 ? 150 : 0;
+                info->blocks_per_cu = per_cu; }
     if (ev_start) { e = hipEventRecord(ev_start, stream); if (e != hipSuccess) return e; }
-    e = R == 8 ? launch_fast<8>(ix, a, n_cus, per_cu, stream) : launch_fast<4>(ix, a, n_cus, per_cu, stream);
+    e = launch_fast(variant, ix, a, n_cus, per_cu, stream);
     if (e != hipSuccess) return e;
     if (ev_mid) { e = hipEventRecord(ev_mid, stream); if (e != hipSuccess) return e; }
     // exact slow path for reads with more than kFastCAP hits (usually none: the kernel reads the count from
@@ -937,7 +1025,7 @@ hipError_t launch_classify(const DevIndex &ix, QueryArgs a, int n_cus, hipStream
         uint64_t grid = (uint64_t)n_cus;
         const uint64_t need = a.n_reads / 32000 + 1;
         if (a.use_lds_hist && grid < need) grid = need;
-        hipLaunchKernelGGL((classify_kernel<kSlowR, kSlowCAP, true>), dim3((unsigned)grid), dim3(kBlock), sm, stream, ix, a);
+        hipLaunchKernelGGL((classify_kernel<kSlowR, kSlowCAP, true, 0, 0>), dim3((unsigned)grid), dim3(kBlock), sm, stream, ix, a);
         e = hipGetLastError();
         if (e != hipSuccess) return e;
         if (ev_stop) e = hipEventRecord(ev_stop, stream);

@@ -15,34 +15,54 @@
 //     fraction of random off-database reads.
 // The small-scale, readable twin is cammiq_amd/synth.py; tests check that files written
 // here decode identically through the oracle, the product and the Python decoder.
+//
+// Built for configs[4]'s size (15 000 genomes, > 10^9 markers): genomes are never stored -- every base is a pure
+// function of (seed, genome, position) through a counter-based generator, so a worker re-creates the genome it is
+// enumerating (3 MB) and a read fetches its 150 bases directly --, markers are 16-byte records partitioned by a
+// bijective mix of their h-mer, sorted and de-duplicated per partition on all cores, and both files of a table
+// are written in place into a mapping of the output file, partition by partition, at bit offsets known from a
+// prefix sum.  File order = ascending mix(h-mer): arbitrary but deterministic, like the reference's robin_hood
+// iteration order is arbitrary.
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cstdint>
 #include <cstdio>
 #include <cmath>
 #include <cstring>
+#include <cstdlib>
 #include <functional>
 #include <string>
 #include <thread>
 #include <vector>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 namespace {
 
-struct Rng {
+constexpr uint64_t kGamma = 0x9E3779B97F4A7C15ull;
+
+inline uint64_t finish(uint64_t z)
+{
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+struct Rng {   // splitmix64: the j-th output is a pure function of (seed, j) -- see rng_at
     uint64_t s;
     explicit Rng(uint64_t seed) : s(seed) {}
-    inline uint64_t next()
-    {
-        uint64_t z = (s += 0x9E3779B97F4A7C15ull);
-        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-        return z ^ (z >> 31);
-    }
+    inline uint64_t next() { return finish(s += kGamma); }
     inline double unit() { return (double)(next() >> 11) * (1.0 / 9007199254740992.0); }
     inline uint64_t below(uint64_t n) { return (uint64_t)(((__uint128_t)next() * n) >> 64); }
 };
 
-inline uint64_t mix(uint64_t a, uint64_t b) { Rng r(a * 0x9E3779B97F4A7C15ull + b); r.next(); return r.next(); }
+// Output of call number j (0-based) of Rng(seed).next(): random access into the stream.
+inline uint64_t rng_at(uint64_t seed, uint64_t j) { return finish(seed + (j + 1) * kGamma); }
+
+inline uint64_t mix(uint64_t a, uint64_t b) { Rng r(a * kGamma + b); r.next(); return r.next(); }
 
 const char kAlpha[4] = {'A', 'C', 'G', 'T'};
 inline uint32_t sym(uint8_t c) { return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : 3; }
@@ -54,30 +74,22 @@ struct Params {
     double frac_deep, pair_share;
 };
 
-struct Marker {      // one key
-    uint64_t hv;     // first h symbols
-    uint32_t rid1, rid2;
-    uint32_t genome; // 0-based source genome
-    uint32_t pos;    // start on the forward strand of the source genome
-    uint8_t len;     // key length
-    uint8_t strand;  // 1: key is the reverse complement of genome[pos, pos+len)
-    uint8_t table;   // 0 unique, 1 doubly unique
-};
+struct World { Params p; };
 
-struct World {
-    Params p;
-    std::vector<std::vector<uint8_t>> genomes;  // ASCII
-    std::vector<std::vector<uint8_t>> shared;   // per genome, per block: 1 = shared with its partner
-};
-
-void thread_pool(unsigned n_items, const std::function<void(unsigned)> &fn)
+unsigned n_workers()
 {
     unsigned hw = std::thread::hardware_concurrency();
-    unsigned nt = std::max(1u, std::min(hw ? hw : 1u, 32u));
-    std::atomic<unsigned> next{0};
+    return std::max(1u, std::min(hw ? hw : 1u, 32u));
+}
+
+// fn(item, worker): items handed out dynamically, worker = index of the thread that runs it.
+void thread_pool(size_t n_items, const std::function<void(size_t, unsigned)> &fn)
+{
+    const unsigned nt = (unsigned)std::min<size_t>(n_workers(), std::max<size_t>(n_items, 1));
+    std::atomic<size_t> next{0};
     std::vector<std::thread> th;
     for (unsigned t = 0; t < nt; t++)
-        th.emplace_back([&] { for (;;) { unsigned i = next.fetch_add(1); if (i >= n_items) break; fn(i); } });
+        th.emplace_back([&, t] { for (;;) { size_t i = next.fetch_add(1); if (i >= n_items) break; fn(i, t); } });
     for (auto &x : th) x.join();
 }
 
@@ -90,28 +102,101 @@ void fill_random(uint8_t *dst, size_t n, Rng &r)
     }
 }
 
-// Key bytes of a marker (forward orientation of the key itself).
-void key_bytes(const World &w, const Marker &m, uint8_t *out)
+// ---- the virtual genomes.  Genome g is the stream Rng(mix(seed, g)), 32 bases per draw, low bits first.  With
+// pair_share > 0 the genomes come in pairs (2i, 2i+1): block k of the pair is shared when draw k of
+// Rng(mix(seed ^ 0xABCDEF, i)) falls below pair_share, and a shared block of the odd genome IS the even genome's.
+inline bool block_shared(const Params &p, uint32_t g, uint32_t blk)
 {
-    const uint8_t *g = w.genomes[m.genome].data() + m.pos;
-    if (!m.strand) memcpy(out, g, m.len);
-    else for (uint32_t i = 0; i < m.len; i++) out[i] = comp(g[m.len - 1 - i]);
+    if (!(p.pair_share > 0) || g >= 2u * (p.n_genomes / 2u)) return false;
+    const uint64_t v = rng_at(mix(p.seed ^ 0xABCDEFull, g / 2u), blk);
+    return (double)(v >> 11) * (1.0 / 9007199254740992.0) < p.pair_share;
 }
 
-struct BitOut {
-    std::vector<uint8_t> buf;
-    uint32_t cur = 0, n = 0;
-    inline void bit(uint32_t b)
-    {
-        cur = (cur << 1) | (b & 1); n++;
-        if (n == 8) { buf.push_back((uint8_t)cur); cur = 0; n = 0; }
+// Bases [st, st + n) of genome g (ASCII).
+void genome_fetch(const Params &p, uint32_t g, uint64_t st, uint32_t n, uint8_t *out)
+{
+    uint64_t pos = st;
+    const uint64_t end = st + n;
+    while (pos < end) {
+        const uint32_t blk = (uint32_t)(pos / p.block);
+        const uint64_t bend = std::min<uint64_t>(end, (uint64_t)(blk + 1) * p.block);
+        const uint32_t src = ((g & 1u) && block_shared(p, g, blk)) ? g - 1u : g;
+        const uint64_t sd = mix(p.seed, src);
+        while (pos < bend) {
+            uint64_t v = rng_at(sd, pos / 32) >> (2 * (pos % 32));
+            const uint64_t stop = std::min<uint64_t>(bend, (pos / 32 + 1) * 32);
+            for (; pos < stop; pos++, v >>= 2) *out++ = (uint8_t)kAlpha[v & 3];
+        }
     }
-    inline void bits(int c, uint32_t v) { for (int i = c - 1; i >= 0; i--) bit((v >> i) & 1); }
+}
+
+// The whole genome g into buf (genome_len bytes) + its blocks' shared flags.
+void genome_materialise(const Params &p, uint32_t g, uint8_t *buf, std::vector<uint8_t> &shared)
+{
+    Rng r(mix(p.seed, g));
+    fill_random(buf, p.genome_len, r);
+    const uint32_t nblk = (p.genome_len + p.block - 1) / p.block;
+    shared.assign(nblk, 0);
+    for (uint32_t k = 0; k < nblk; k++)
+        if (block_shared(p, g, k)) {
+            shared[k] = 1;
+            if (g & 1u) {
+                const size_t lo = (size_t)k * p.block, hi = std::min<size_t>(lo + p.block, p.genome_len);
+                genome_fetch(p, g, lo, (uint32_t)(hi - lo), buf + lo);
+            }
+        }
+}
+
+// One key: 16 bytes.  refIDs follow from genome and table (unique: g+1; doubly unique: g+1, g+2).
+struct Marker {
+    uint64_t hv;     // first h symbols of the key
+    uint32_t pos;    // start on the forward strand of the source genome
+    uint32_t gsl;    // genome << 9 | strand << 8 | key length
+    inline uint32_t genome() const { return gsl >> 9; }
+    inline uint32_t strand() const { return (gsl >> 8) & 1u; }
+    inline uint32_t len() const { return gsl & 255u; }
 };
 
-inline void be(std::vector<uint8_t> &o, uint64_t v, int nbytes)
+// File order: ascending in a bijective mix of the h-mer (equal h-mers stay adjacent for the duplicate test).
+inline uint64_t order_key(uint64_t hv) { return finish(hv * kGamma + 0x1234567ull); }
+constexpr unsigned kPartBits = 10, kParts = 1u << kPartBits;
+
+// Key symbols h .. len-1 of a marker (the trie part), 0..3, key orientation.
+void deep_symbols(const Params &p, const Marker &m, uint8_t *out)
 {
-    for (int i = nbytes - 1; i >= 0; i--) o.push_back((uint8_t)(v >> (8 * i)));
+    uint8_t tmp[256];
+    const uint32_t len = m.len(), d = len - p.h;
+    if (!m.strand()) {
+        genome_fetch(p, m.genome(), (uint64_t)m.pos + p.h, d, tmp);
+        for (uint32_t i = 0; i < d; i++) out[i] = (uint8_t)sym(tmp[i]);
+    } else {   // key = reverse complement of genome[pos, pos + len): key[h + i] = comp(genome[pos + len - 1 - h - i])
+        genome_fetch(p, m.genome(), m.pos, d, tmp);
+        for (uint32_t i = 0; i < d; i++) out[i] = (uint8_t)(3u - sym(tmp[d - 1 - i]));
+    }
+}
+
+struct OutMap {   // output file, written in place
+    uint8_t *p = nullptr;
+    size_t n = 0;
+    bool open(const std::string &path, size_t bytes)
+    {
+        int fd = ::open(path.c_str(), O_RDWR | O_CREAT | O_TRUNC, 0644);
+        if (fd < 0) return false;
+        n = bytes;
+        if (bytes == 0) { ::close(fd); return true; }
+        if (ftruncate(fd, (off_t)bytes) != 0) { ::close(fd); return false; }
+        void *m = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+        ::close(fd);
+        if (m == MAP_FAILED) return false;
+        p = (uint8_t *)m;
+        return true;
+    }
+    ~OutMap() { if (p) munmap(p, n); }
+};
+
+inline void be(uint8_t *&o, uint64_t v, int nbytes)
+{
+    for (int i = nbytes - 1; i >= 0; i--) *o++ = (uint8_t)(v >> (8 * i));
 }
 
 }  // namespace
@@ -133,36 +218,23 @@ struct cqs_params {
 
 void *cqs_create(const cqs_params *pp)
 {
+    if (pp->n_genomes >= (1u << 23) || pp->lmax > 255 || pp->h > 31 || pp->h > pp->k) return nullptr;
     World *w = new World();
     w->p = Params{pp->seed, pp->n_genomes, pp->genome_len, pp->k, pp->h, pp->lmax, pp->marker_every,
                   pp->block ? pp->block : 2048, pp->frac_deep, pp->pair_share};
-    const Params &p = w->p;
-    w->genomes.resize(p.n_genomes);
-    w->shared.resize(p.n_genomes);
-    const uint32_t nblk = (p.genome_len + p.block - 1) / p.block;
-    thread_pool(p.n_genomes, [&](unsigned g) {
-        w->genomes[g].resize(p.genome_len);
-        Rng r(mix(p.seed, g));
-        fill_random(w->genomes[g].data(), p.genome_len, r);
-        w->shared[g].assign(nblk, 0);
-    });
-    if (p.pair_share > 0) {
-        // genome 2i+1 copies the shared blocks of genome 2i
-        thread_pool(p.n_genomes / 2, [&](unsigned i) {
-            uint32_t a = 2 * i, b = 2 * i + 1;
-            Rng r(mix(p.seed ^ 0xABCDEFull, i));
-            for (uint32_t k = 0; k < nblk; k++)
-                if (r.unit() < p.pair_share) {
-                    w->shared[a][k] = w->shared[b][k] = 1;
-                    size_t lo = (size_t)k * p.block, hi = std::min<size_t>(lo + p.block, p.genome_len);
-                    memcpy(w->genomes[b].data() + lo, w->genomes[a].data() + lo, hi - lo);
-                }
-        });
-    }
     return w;
 }
 
 void cqs_free(void *h) { delete (World *)h; }
+
+/* Bases [start, start+n) of genome g (0-based), ASCII: what a FASTA of the world would hold. */
+int cqs_genome_bases(void *hh, uint32_t g, uint64_t start, uint32_t n, uint8_t *out)
+{
+    World &w = *(World *)hh;
+    if (g >= w.p.n_genomes || start + n > w.p.genome_len) return -1;
+    genome_fetch(w.p, g, start, n, out);
+    return 0;
+}
 
 /* Writes index_u (and index_d when path_d != NULL and pair_share > 0).  Returns 0. */
 int cqs_write_index(void *hh, const char *path_u, const char *path_d, uint64_t *n_leaves_u, uint64_t *n_leaves_d)
@@ -170,11 +242,30 @@ int cqs_write_index(void *hh, const char *path_u, const char *path_d, uint64_t *
     World &w = *(World *)hh;
     const Params &p = w.p;
     const bool both = path_d && path_d[0] && p.pair_share > 0;
-    std::vector<std::vector<Marker>> per(p.n_genomes);
-    thread_pool(p.n_genomes, [&](unsigned g) {
+    const unsigned nt = n_workers();
+    const bool timing = getenv("CQS_TIMING") != nullptr;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t0 = now();
+    auto lap = [&](const char *what) { if (timing) { const double t1 = now(); fprintf(stderr, "[cq_synth] %-28s %7.2f s\n", what, t1 - t0); t0 = t1; } };
+    // ---- 1. enumerate: worker t keeps kParts bins per table; a genome is re-created, scanned and forgotten
+    std::vector<std::vector<std::vector<Marker>>> bins[2];
+    for (int t = 0; t < 2; t++) bins[t].assign(nt, std::vector<std::vector<Marker>>(kParts));
+    {   // reserve what a bin is expected to take (no doubling copies of multi-GB totals)
+        const double total = 2.0 * p.genome_len / std::max(1u, p.marker_every) * p.n_genomes;
+        const double sh = both ? p.pair_share : 0.0;
+        const size_t r0 = (size_t)(total * (1.0 - sh) / nt / kParts * 1.2) + 16, r1 = (size_t)(total * sh / 2 / nt / kParts * 1.2) + 16;
+        thread_pool(nt, [&](size_t t, unsigned) {
+            for (unsigned q = 0; q < kParts; q++) { bins[0][t][q].reserve(r0); if (sh > 0) bins[1][t][q].reserve(r1); }
+        });
+    }
+    std::vector<std::vector<uint8_t>> gbuf(nt), gshared(nt);
+    thread_pool(p.n_genomes, [&](size_t gi, unsigned t) {
+        const uint32_t g = (uint32_t)gi;
+        if (gbuf[t].size() < p.genome_len) gbuf[t].resize(p.genome_len);
+        genome_materialise(p, g, gbuf[t].data(), gshared[t]);
+        const uint8_t *G = gbuf[t].data();
+        const std::vector<uint8_t> &shared = gshared[t];
         Rng r(mix(p.seed ^ 0x5151ull, g));
-        std::vector<Marker> &out = per[g];
-        const uint8_t *G = w.genomes[g].data();
         for (int strand = 0; strand < 2; strand++) {
             uint64_t pos = r.below(p.marker_every);
             for (;;) {
@@ -187,87 +278,113 @@ int cqs_write_index(void *hh, const char *path_u, const char *path_d, uint64_t *
                 const uint32_t b0 = (uint32_t)(pos / p.block), b1 = (uint32_t)((pos + len - 1) / p.block);
                 uint64_t gap = 1 + r.below(2ull * p.marker_every - 1);
                 if (b0 == b1) {   // keys never straddle a block boundary
-                    const bool sh = w.shared[g][b0] != 0;
+                    const bool sh = shared[b0] != 0;
                     // a shared block is indexed once, from the even genome of the pair
                     if (!sh || (both && (g & 1u) == 0)) {
-                        Marker m;
-                        m.genome = g; m.pos = (uint32_t)pos; m.len = (uint8_t)len; m.strand = (uint8_t)strand;
-                        m.table = sh ? 1 : 0;
-                        m.rid1 = g + 1; m.rid2 = sh ? g + 2 : 0;
                         uint64_t hv = 0;
                         if (!strand) for (uint32_t i = 0; i < p.h; i++) hv = (hv << 2) | sym(G[pos + i]);
                         else for (uint32_t i = 0; i < p.h; i++) hv = (hv << 2) | (3u - sym(G[pos + len - 1 - i]));
-                        m.hv = hv;
-                        out.push_back(m);
+                        Marker m{hv, (uint32_t)pos, (g << 9) | ((uint32_t)strand << 8) | len};
+                        bins[sh ? 1 : 0][t][order_key(hv) >> (64 - kPartBits)].push_back(m);
                     }
                 }
                 pos += gap;
             }
         }
     });
+    gbuf.clear(); gshared.clear();
+    lap("enumerate markers");
+
     for (int table = 0; table < (both ? 2 : 1); table++) {
-        std::vector<Marker> all;
-        size_t tot = 0;
-        for (auto &v : per) tot += v.size();
-        all.reserve(tot);
-        for (auto &v : per) for (auto &m : v) if (m.table == table) all.push_back(m);
-        // one key per bucket: sort by hv, drop every bucket that occurs more than once
-        std::sort(all.begin(), all.end(), [](const Marker &a, const Marker &b) { return a.hv < b.hv; });
-        size_t wr = 0;
-        for (size_t i = 0; i < all.size();) {
-            size_t j = i + 1;
-            while (j < all.size() && all[j].hv == all[i].hv) j++;
-            if (j == i + 1) all[wr++] = all[i];
-            i = j;
-        }
-        all.resize(wr);
-        // deterministic shuffle: file order is arbitrary in the reference (robin_hood iteration)
-        {
-            Rng r(mix(p.seed ^ 0x77ull, table));
-            for (size_t i = all.size(); i > 1; i--) std::swap(all[i - 1], all[r.below(i)]);
-        }
-        BitOut aux;
-        std::vector<uint8_t> ints;
-        ints.reserve(all.size() * (table ? 20 : 14) + 16);
-        aux.buf.reserve(all.size() + 64);
-        aux.bit(table ? 1 : 0);
-        aux.bits(7, 64);
-        aux.bits(8, p.h);
-        uint8_t key[256];
-        for (const Marker &m : all) {
-            be(ints, m.hv, 8);
-            key_bytes(w, m, key);
-            // single-path trie below the bucket root: for every inner level '1' then the four
-            // child slots ('0' except the path symbol, which recurses); the leaf is '1 0000'.
-            // Pre-order means the closing '0's of a level come after the whole subtree.
-            uint32_t depth = m.len - p.h;
-            std::vector<uint8_t> closing;  // zeros still owed per level
-            for (uint32_t d = 0; d < depth; d++) {
-                aux.bit(1);
-                uint32_t s = sym(key[p.h + d]);
-                for (uint32_t c = 0; c < s; c++) aux.bit(0);
-                closing.push_back((uint8_t)(3 - s));
+        // ---- 2. per partition: gather the workers' bins, sort by order_key, drop every h-mer that occurs more than once
+        //         (one key per bucket: two keys with one h-mer prefix would need a branching trie)
+        std::vector<std::vector<Marker>> part(kParts);
+        std::vector<uint64_t> nbits(kParts, 0), nbytes(kParts, 0);
+        const size_t rec = table ? 12 : 6;
+        thread_pool(kParts, [&](size_t q, unsigned) {
+            std::vector<Marker> &all = part[q];
+            size_t tot = 0;
+            for (unsigned t = 0; t < nt; t++) tot += bins[table][t][q].size();
+            all.reserve(tot);
+            for (unsigned t = 0; t < nt; t++) {
+                std::vector<Marker> &b = bins[table][t][q];
+                all.insert(all.end(), b.begin(), b.end());
+                std::vector<Marker>().swap(b);
             }
-            aux.bit(1); aux.bit(0); aux.bit(0); aux.bit(0); aux.bit(0);
-            for (size_t d = closing.size(); d-- > 0;)
-                for (uint8_t c = 0; c < closing[d]; c++) aux.bit(0);
-            if (table) { be(ints, m.rid1, 4); be(ints, m.rid2, 4); be(ints, 1, 2); be(ints, 1, 2); }
-            else { be(ints, m.rid1, 4); be(ints, 1, 2); }
+            std::sort(all.begin(), all.end(), [](const Marker &a, const Marker &b) {
+                const uint64_t ka = order_key(a.hv), kb = order_key(b.hv);
+                return ka != kb ? ka < kb : (a.gsl != b.gsl ? a.gsl < b.gsl : a.pos < b.pos);
+            });
+            size_t wr = 0;
+            for (size_t i = 0; i < all.size();) {
+                size_t j = i + 1;
+                while (j < all.size() && all[j].hv == all[i].hv) j++;
+                if (j == i + 1) all[wr++] = all[i];
+                i = j;
+            }
+            all.resize(wr);
+            uint64_t bits = 0;
+            for (const Marker &m : all) bits += 5u + 4u * (m.len() - p.h);   // inner level: '1' + 4 child slots; leaf: '1 0000'
+            nbits[q] = bits;
+            nbytes[q] = (uint64_t)all.size() * (8 + rec);
+        });
+        lap(table ? "sort + dedupe (d)" : "sort + dedupe (u)");
+        // ---- 3. offsets.  aux: 16 header bits, the partitions' bits, 72 one-bits, the final partial byte dropped
+        //         (binaryio.cpp:115-118 as the reference's writer leaves it); ints: records, END64, 0xFFFF
+        std::vector<uint64_t> bit0(kParts + 1), byte0(kParts + 1);
+        bit0[0] = 16; byte0[0] = 0;
+        uint64_t n_leaves = 0;
+        for (unsigned q = 0; q < kParts; q++) {
+            bit0[q + 1] = bit0[q] + nbits[q];
+            byte0[q + 1] = byte0[q] + nbytes[q];
+            n_leaves += part[q].size();
         }
-        for (int i = 0; i < 72; i++) aux.bit(1);
-        be(ints, 0xFFFFFFFFFFFFFFFFull, 8);
-        be(ints, 0xFFFF, 2);
-        std::string path = table ? path_d : path_u;
-        FILE *f = fopen(path.c_str(), "wb");
-        if (!f) return -1;
-        fwrite(ints.data(), 1, ints.size(), f);
-        fclose(f);
-        f = fopen((path + ".aux").c_str(), "wb");
-        if (!f) return -1;
-        fwrite(aux.buf.data(), 1, aux.buf.size(), f);
-        fclose(f);
-        if (table == 0 && n_leaves_u) *n_leaves_u = all.size();
-        if (table == 1 && n_leaves_d) *n_leaves_d = all.size();
+        const uint64_t aux_bytes = (bit0[kParts] + 72) / 8, int_bytes = byte0[kParts] + 10;
+        const std::string path = table ? path_d : path_u;
+        OutMap fi, fa;
+        if (!fi.open(path, int_bytes) || !fa.open(path + ".aux", aux_bytes)) return -1;
+        // ---- 4. emit in place.  A partition's bit range shares its first and last byte with its neighbours: those
+        //         two bytes are OR-ed in afterwards, everything between is written by the partition's worker alone.
+        std::vector<uint64_t> edge_off(2 * kParts, ~0ull);
+        std::vector<uint8_t> edge_val(2 * kParts, 0);
+        thread_pool(kParts, [&](size_t q, unsigned) {
+            const std::vector<Marker> &all = part[q];
+            uint8_t *o = fi.p + byte0[q];
+            const uint64_t b_lo = bit0[q], b_hi = bit0[q + 1];
+            const uint64_t first = b_lo / 8, last = b_hi ? (b_hi - 1) / 8 : 0;
+            std::vector<uint8_t> loc(b_hi > b_lo ? (size_t)(last - first + 1) : 0, 0);
+            uint64_t bp = b_lo - first * 8;   // bit cursor within loc
+            auto put = [&](uint32_t bit) { if (bit) loc[bp >> 3] |= (uint8_t)(0x80u >> (bp & 7)); bp++; };
+            uint8_t syms[256];
+            for (const Marker &m : all) {
+                be(o, m.hv, 8);
+                const uint32_t depth = m.len() - p.h;
+                if (depth) deep_symbols(p, m, syms);
+                // single-path trie below the bucket root, pre-order: per inner level '1', then '0' for the child slots
+                // before the path symbol; the leaf is '1 0000'; the slots after the path symbol close level by level
+                for (uint32_t d = 0; d < depth; d++) { put(1); for (uint32_t c = 0; c < syms[d]; c++) put(0); }
+                put(1); put(0); put(0); put(0); put(0);
+                for (uint32_t d = depth; d-- > 0;) for (uint32_t c = syms[d]; c < 3; c++) put(0);
+                const uint32_t g = m.genome();
+                if (table) { be(o, g + 1, 4); be(o, g + 2, 4); be(o, 1, 2); be(o, 1, 2); }
+                else { be(o, g + 1, 4); be(o, 1, 2); }
+            }
+            if (loc.empty()) return;
+            if (loc.size() > 2) memcpy(fa.p + first + 1, loc.data() + 1, loc.size() - 2);
+            edge_off[2 * q] = first; edge_val[2 * q] = loc[0];
+            if (loc.size() > 1) { edge_off[2 * q + 1] = last; edge_val[2 * q + 1] = loc.back(); }
+        });
+        fa.p[0] = (uint8_t)((table ? 0x80u : 0u) | 64u);
+        fa.p[1] = (uint8_t)p.h;
+        for (size_t e = 0; e < edge_off.size(); e++)
+            if (edge_off[e] != ~0ull && edge_off[e] < aux_bytes) fa.p[edge_off[e]] |= edge_val[e];
+        for (uint64_t b = bit0[kParts]; b < aux_bytes * 8; b++) fa.p[b >> 3] |= (uint8_t)(0x80u >> (b & 7));
+        uint8_t *o = fi.p + byte0[kParts];
+        be(o, 0xFFFFFFFFFFFFFFFFull, 8);
+        be(o, 0xFFFF, 2);
+        lap(table ? "emit (d)" : "emit (u)");
+        if (table == 0 && n_leaves_u) *n_leaves_u = n_leaves;
+        if (table == 1 && n_leaves_d) *n_leaves_d = n_leaves;
     }
     if (!both && n_leaves_d) *n_leaves_d = 0;
     return 0;
@@ -284,7 +401,7 @@ int cqs_make_reads_at(void *hh, uint64_t seed, uint64_t first, uint64_t n, uint3
     if (len > p.genome_len) return -1;
     const unsigned chunks = 256;
     const double inv_log_q = (err > 0 && err < 1) ? 1.0 / std::log1p(-err) : 0.0;
-    thread_pool(chunks, [&](unsigned c) {
+    thread_pool(chunks, [&](size_t c, unsigned) {
         uint64_t lo = n * c / chunks, hi = n * (c + 1) / chunks;
         for (uint64_t i = lo; i < hi; i++) {
             Rng r(mix(seed, first + i));
@@ -292,9 +409,14 @@ int cqs_make_reads_at(void *hh, uint64_t seed, uint64_t first, uint64_t n, uint3
             if (r.unit() < frac_random) { fill_random(out, len, r); continue; }
             uint32_t g = (uint32_t)r.below(p.n_genomes);
             uint64_t st = r.below((uint64_t)p.genome_len - len + 1);
-            const uint8_t *G = w.genomes[g].data() + st;
-            if (r.next() & 1) for (uint32_t j = 0; j < len; j++) out[j] = comp(G[len - 1 - j]);
-            else memcpy(out, G, len);
+            uint8_t G[256 + 8];
+            const bool big = len > 256;
+            std::vector<uint8_t> gl;
+            uint8_t *Gp = G;
+            if (big) { gl.resize(len); Gp = gl.data(); }
+            genome_fetch(p, g, st, len, Gp);
+            if (r.next() & 1) for (uint32_t j = 0; j < len; j++) out[j] = comp(Gp[len - 1 - j]);
+            else memcpy(out, Gp, len);
             if (err >= 1) { for (uint32_t j = 0; j < len; j++) out[j] = (uint8_t)kAlpha[(sym(out[j]) + 1 + r.below(3)) & 3]; }
             else if (err > 0)
                 for (double j = std::floor(std::log(1.0 - r.unit()) * inv_log_q); j < (double)len;

@@ -225,7 +225,9 @@ int cq_query_device(cq_index *idx, int mode, const uint32_t *d_packed, const uin
 
 /* SC mode: copy out and clear the pair counters accumulated by cq_query_device.  Synchronises.
  * With pair_a == NULL only *n_pairs is written (nothing copied, nothing cleared); with arrays that
- * are too small: CQ_ERR_LIMIT, *n_pairs = the number needed, nothing cleared -- call again. */
+ * are too small: CQ_ERR_LIMIT, *n_pairs = the number needed, nothing cleared -- call again.
+ * The host-fed entries (cq_query*, cq_multi_query*) start every SC-mode query from an EMPTY map:
+ * pairs kept after a CQ_ERR_LIMIT can be fetched here only until the next query on the handle. */
 int cq_pairs_fetch(cq_index *idx, uint32_t *pair_a, uint32_t *pair_b, uint64_t *pair_cnt,
                    uint64_t pair_cap, uint64_t *n_pairs);
 
@@ -241,6 +243,24 @@ int cq_pairs_reserve(cq_index *idx, uint64_t n_slots);
  * cq_last_kernel_ms = their sum. */
 int cq_last_kernel_times(cq_index *idx, float *fast_ms, float *slow_ms);
 int cq_last_kernel_ms(cq_index *idx, float *ms);
+
+/* Which instantiation of the classify kernel the most recent cq_query_device launch on this handle ran
+ * (profiling records name the kernel they measured by this, not by a constant): reads per wave sub-tile
+ * (8; 4 for reads >~ 235 bp), hit slots per read, per-genome counters in an LDS histogram (1) or as
+ * global atomics (0), and whether the build with CAMMiQ's default hash length 26
+ * (/root/reference/src/main.cpp:335-346) and the batch's read length (100 / 150) folded in as
+ * compile-time constants was used (same results; tests run both). */
+typedef struct cq_launch_info {
+    int32_t reads_per_subtile;
+    int32_t hit_slots;
+    int32_t lds_hist;
+    int32_t fixed_shape;
+    int32_t fixed_hash_len;   /* 0 unless fixed_shape */
+    int32_t fixed_read_len;   /* 0 unless fixed_shape */
+    int32_t blocks_per_cu;    /* resident workgroups per CU the persistent grid was sized for */
+    int32_t reserved;
+} cq_launch_info;
+int cq_last_launch_info(cq_index *idx, cq_launch_info *out);
 
 /* ---- multi-GPU -----------------------------------------------------------------------------
  * No reference analogue: the reference's one parallel axis is the OpenMP loop over reads

@@ -613,6 +613,20 @@ static void cqo_classify_read(const cqo_index *ix, int mode, const uint8_t *read
         }
 #pragma omp atomic
         acc->branch[br] += 1;
+    } else if (locked == 3) {
+        /* SURVEY.md 8(d)'s optimised CPU variant: `acc` is this THREAD's own counter block (merged after the
+         * loop by cqo_query_variant), so nothing here is shared except the per-leaf rcount, which stays one
+         * atomic add per distinct hit of a counted read.  Removes the lock of query.cpp:742-878 altogether. */
+        acc->nundet += (uint64_t)d_nundet; acc->nconf += (uint64_t)d_nconf;
+        for (int k = 0; k < n_inc_u; k++) acc->cnt_u[inc_u[k]]++;
+        for (int k = 0; k < n_inc_d; k++) acc->cnt_d[inc_d[k]]++;
+        if (bump && mode == CQO_MODE_P)
+            for (int k = 0; k < np; k++) {
+#pragma omp atomic
+                pnodes[k]->rcount += 1;
+            }
+        if (add_pb && mode == CQO_MODE_SC) cqo_pb_add(acc, rid_pairs[0]);
+        acc->branch[br]++;
     } else if (locked) {
 #pragma omp critical
         {
@@ -660,6 +674,20 @@ static int64_t cqo_check_reads(const cqo_index *ix, const uint8_t *bases, const 
  * Returns 0, or -(1+index) of the first read outside the parity domain, or -1e9
  * for a refID above n_genomes.
  */
+enum { CQO_VAR_SERIAL = 0, CQO_VAR_CRITICAL = 1, CQO_VAR_ATOMIC = 2, CQO_VAR_THREAD_LOCAL = 3 };
+
+/* variant: CQO_VAR_SERIAL (query64_p), CQO_VAR_CRITICAL (query64mt_p as written: one global critical section per
+ * read), CQO_VAR_ATOMIC (same loop, every shared counter an atomic), CQO_VAR_THREAD_LOCAL (per-thread cnt_u /
+ * cnt_d / nundet / nconf / branch / read_cnts_b merged after the loop, rcount via atomics: SURVEY.md 8(d)'s
+ * "optimised variant (thread-local counters)").  All four give identical outputs (tests/test_oracle.py). */
+int64_t cqo_query_variant(cqo_index *ix, int mode, int nthreads, int variant,
+                          const uint8_t *bases, const uint64_t *offsets, uint64_t n_reads,
+                          uint32_t n_genomes,
+                          uint64_t *cnt_u, uint64_t *cnt_d, uint32_t *rcount_u, uint32_t *rcount_d,
+                          uint64_t *scal, uint64_t *branch,
+                          uint32_t *pair_a, uint32_t *pair_b, uint64_t *pair_cnt, uint64_t pair_cap,
+                          uint64_t *n_pairs);
+
 int64_t cqo_query(cqo_index *ix, int mode, int nthreads,
                   const uint8_t *bases, const uint64_t *offsets, uint64_t n_reads,
                   uint32_t n_genomes,
@@ -667,6 +695,19 @@ int64_t cqo_query(cqo_index *ix, int mode, int nthreads,
                   uint64_t *scal, uint64_t *branch,
                   uint32_t *pair_a, uint32_t *pair_b, uint64_t *pair_cnt, uint64_t pair_cap,
                   uint64_t *n_pairs)
+{
+    const int variant = (nthreads >= 0 && nthreads <= 1) ? CQO_VAR_SERIAL : nthreads < 0 ? CQO_VAR_ATOMIC : CQO_VAR_CRITICAL;
+    return cqo_query_variant(ix, mode, nthreads < 0 ? -nthreads : nthreads, variant, bases, offsets, n_reads, n_genomes,
+                             cnt_u, cnt_d, rcount_u, rcount_d, scal, branch, pair_a, pair_b, pair_cnt, pair_cap, n_pairs);
+}
+
+int64_t cqo_query_variant(cqo_index *ix, int mode, int nthreads, int variant,
+                          const uint8_t *bases, const uint64_t *offsets, uint64_t n_reads,
+                          uint32_t n_genomes,
+                          uint64_t *cnt_u, uint64_t *cnt_d, uint32_t *rcount_u, uint32_t *rcount_d,
+                          uint64_t *scal, uint64_t *branch,
+                          uint32_t *pair_a, uint32_t *pair_b, uint64_t *pair_cnt, uint64_t pair_cap,
+                          uint64_t *n_pairs)
 {
     if (cqo_max_refid(ix) > n_genomes) return -1000000000LL;
     int64_t bad = cqo_check_reads(ix, bases, offsets, n_reads);
@@ -680,15 +721,43 @@ int64_t cqo_query(cqo_index *ix, int mode, int nthreads,
     for (int t = 0; t < 2; t++)
         for (uint64_t i = 0; i < ix->ht[t].leaf_cnt; i++) ix->ht[t].leaves[i]->rcount = 0;
 
-    if (nthreads >= 0 && nthreads <= 1) {
+    if (nthreads < 1) nthreads = 1;
+    if (variant == CQO_VAR_SERIAL) {
         for (uint64_t r = 0; r < n_reads; r++)
             cqo_classify_read(ix, mode, bases + offsets[r], (size_t)(offsets[r + 1] - offsets[r]), &acc, 0);
-    } else {
-        /* nthreads > 1: one global critical section per update, as query64mt_p does;
-         * nthreads < 0: |nthreads| threads with atomic counter updates (fair CPU variant). */
-        const int lock_mode = nthreads < 0 ? 2 : 1;
+    } else if (variant == CQO_VAR_THREAD_LOCAL) {
 #ifdef _OPENMP
-        omp_set_num_threads(nthreads < 0 ? -nthreads : nthreads);
+        omp_set_num_threads(nthreads);
+#endif
+#pragma omp parallel
+        {
+            cqo_acc loc;
+            memset(&loc, 0, sizeof loc);
+            loc.cnt_u = (uint64_t *)calloc((size_t)n_genomes + 1, sizeof *loc.cnt_u);
+            loc.cnt_d = (uint64_t *)calloc((size_t)n_genomes + 1, sizeof *loc.cnt_d);
+#pragma omp for schedule(dynamic, 512) nowait
+            for (int64_t r = 0; r < (int64_t)n_reads; r++)
+                cqo_classify_read(ix, mode, bases + offsets[r], (size_t)(offsets[r + 1] - offsets[r]), &loc, 3);
+#pragma omp critical
+            {
+                for (uint32_t g = 0; g <= n_genomes; g++) { acc.cnt_u[g] += loc.cnt_u[g]; acc.cnt_d[g] += loc.cnt_d[g]; }
+                acc.nundet += loc.nundet; acc.nconf += loc.nconf;
+                for (int b = 0; b < CQO_BR_N; b++) acc.branch[b] += loc.branch[b];
+                for (uint64_t i = 0; i < loc.npb; i++) {
+                    uint64_t j = 0;
+                    while (j < acc.npb && !(acc.pb[j].a == loc.pb[i].a && acc.pb[j].b == loc.pb[i].b)) j++;
+                    if (j < acc.npb) acc.pbc[j] += loc.pbc[i];
+                    else { cqo_pb_add(&acc, loc.pb[i]); acc.pbc[acc.npb - 1] = loc.pbc[i]; }
+                }
+            }
+            free(loc.cnt_u); free(loc.cnt_d); free(loc.pb); free(loc.pbc);
+        }
+    } else {
+        /* CQO_VAR_CRITICAL: one global critical section per update, as query64mt_p does;
+         * CQO_VAR_ATOMIC: the same loop with atomic counter updates. */
+        const int lock_mode = variant == CQO_VAR_ATOMIC ? 2 : 1;
+#ifdef _OPENMP
+        omp_set_num_threads(nthreads);
 #endif
 #pragma omp parallel for
         for (int64_t r = 0; r < (int64_t)n_reads; r++)

@@ -44,9 +44,15 @@ def lib():
         L.cqo_query.restype = C.c_int64
         L.cqo_query.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64,
                                 C.c_uint32] + [C.c_void_p] * 9 + [C.c_uint64, C.c_void_p]
+        L.cqo_query_variant.restype = C.c_int64
+        L.cqo_query_variant.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64,
+                                        C.c_uint32] + [C.c_void_p] * 9 + [C.c_uint64, C.c_void_p]
         L.cqo_omp_max_threads.restype = C.c_int
         _LIB = L
     return _LIB
+
+
+VARIANTS = ["serial", "critical", "atomic", "thread_local"]
 
 
 def _p(a):
@@ -71,7 +77,10 @@ class OracleIndex:
         return dict(refID1=r1, refID2=r2, depth=dp, ucount1=c1, ucount2=c2)
 
     def query(self, bases: np.ndarray, offsets: np.ndarray, n_genomes: int, mode: int = 0,
-              nthreads: int = 1):
+              nthreads: int = 1, variant: str | None = None):
+        """nthreads: 1 serial (query64_p); > 1 OpenMP with one global critical section (query64mt_p);
+        < 0 atomics.  variant ("serial" | "critical" | "atomic" | "thread_local") overrides that choice and
+        takes |nthreads| threads: "thread_local" = per-thread counters merged after the loop."""
         n = len(offsets) - 1
         bases = np.ascontiguousarray(bases, np.uint8)
         offsets = np.ascontiguousarray(offsets, np.uint64)
@@ -81,9 +90,15 @@ class OracleIndex:
         cap = 1 << 16
         pa = np.zeros(cap, np.uint32); pb = np.zeros(cap, np.uint32); pc = np.zeros(cap, np.uint64)
         npairs = np.zeros(1, np.uint64)
-        rc = lib().cqo_query(self.h, mode, nthreads, _p(bases), _p(offsets), n, n_genomes,
-                             _p(cu), _p(cd), _p(ru), _p(rd), _p(scal), _p(br),
-                             _p(pa), _p(pb), _p(pc), cap, _p(npairs))
+        if variant is None:
+            rc = lib().cqo_query(self.h, mode, nthreads, _p(bases), _p(offsets), n, n_genomes,
+                                 _p(cu), _p(cd), _p(ru), _p(rd), _p(scal), _p(br),
+                                 _p(pa), _p(pb), _p(pc), cap, _p(npairs))
+        else:
+            v = VARIANTS.index(variant)
+            rc = lib().cqo_query_variant(self.h, mode, abs(nthreads), v, _p(bases), _p(offsets), n, n_genomes,
+                                         _p(cu), _p(cd), _p(ru), _p(rd), _p(scal), _p(br),
+                                         _p(pa), _p(pb), _p(pc), cap, _p(npairs))
         if rc != 0:
             raise ValueError(f"oracle: read {-rc - 1} outside the parity domain" if rc > -10**9
                              else "oracle: refID above n_genomes")

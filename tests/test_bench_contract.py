@@ -32,11 +32,51 @@ def test_single_gpu_line():
     ro = j["roofline"]
     assert ro["bound"] == "hbm" and ro["unit"] == "GB/s" and ro["frac"] > 0 and abs(ro["frac"] - ro["achieved"] / ro["peak"]) < 1e-3
     assert ro["traffic"] is None            # no PMC pass exists for a toy workload: never a made-up number
+    assert ro["algorithmic_T"] == 1 and ro["kernel"].startswith("classify_kernel<8,16,false,") and len(ro["kernel_ms_runs"]) == 2
+    assert ro["kernel_launch"]["fixed_shape"] == 1      # h = 26, 100-bp batch: the instantiation with the shape folded in
+    assert "frac_at_profiled_ms" not in ro              # ... and no profiled duration either
     cb = j["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and j["parity_checked_reads"] == 20000
+    assert cb["value_thread_local"] > 0 and cb["value_atomic"] > 0 and cb["host_cores_online"] >= cb["cores"]
     o = j["outcome"]
     assert o["reads"] == 2 * 200000 and o["nskipped"] == 0
     assert j["host_fed"]["Mreads_s"] > 0 and j["host_fed"]["bytes_per_read_on_the_wire"] == 26
+    assert j["value_survey_8d_bracket"] == j["host_fed"]["Mreads_s"]
+
+
+def test_multi_leg_on_one_device():
+    """--multi-leg on: the same host-fed query through cq_multi_* (here the one-rank communicator) equals the
+    single-device counts and is reported in the line."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + TOY + ["--multi-leg", "on", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = _line(r.stdout)
+    assert j["multi_in_process"]["equals_single_device"] is True and j["multi_in_process"]["devices"] == [0]
+
+
+def test_gpus_2_starts_its_own_ranks():
+    """`python bench.py --gpus 2` WITHOUT torchrun: the launcher in bench.py starts two fresh ranks before it touches
+    torch or the GPU, forwards rank 0's line and returns the ranks' status (rehearsal mode: both ranks on cuda:0,
+    control plane and reduction over gloo -- RCCL needs one GPU per rank)."""
+    env = dict(os.environ, CAMMIQ_BENCH_REHEARSAL="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + TOY, capture_output=True, text=True,
+                       timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = _line(r.stdout)
+    assert j["n_gpus"] == 2 and "sharded x2" in j["config"]["parallelism"] and "gloo" in j["config"]["parallelism"]
+    assert j["outcome"]["reads"] == 2 * 2 * 200000
+
+
+def test_a_failing_rank_fails_the_launcher():
+    """No fallback collective and no swallowed failures: a rank that cannot run ends `--gpus 2` non-zero."""
+    env = dict(os.environ, CAMMIQ_BENCH_REHEARSAL="1", CAMMIQ_LIB="/nonexistent/libcammiq_hip.so")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + TOY, capture_output=True, text=True,
+                       timeout=300, env=env)
+    assert r.returncode != 0 and not [l for l in r.stdout.splitlines() if l.startswith("{")]
 
 
 def test_two_ranks_rehearsal_over_gloo():

@@ -361,3 +361,37 @@ def test_reads_per_sub_tile_do_not_change_the_result(tmp_path, monkeypatch, rl):
                 got = cq.Index(pu, pd, device=0).query(b, o, len(gen), mode=mode)
                 assert_same(got, ref, f"rl={rl} R={R} hist={hist} mode={mode}", rcount=(mode == cq.MODE_P))
                 assert got["pairs"] == ref["pairs"]
+
+
+@pytest.mark.parametrize("rl", [100, 150])
+def test_fixed_shape_instantiation_equals_the_generic_kernel(tmp_path, monkeypatch, rl):
+    """h = 26 (CAMMiQ's default) with a batch whose longest read is 100 / 150 bp runs the instantiation that has hash
+    length and batch shape folded in as constants; CAMMIQ_NO_FIXED_SHAPE=1 forces the generic one.  Both against
+    the oracle: deep keys, mixed read lengths below the batch maximum (ragged windows), both modes, counters in
+    LDS and as global atomics."""
+    gen = synth.clade_genomes(77, 3, 4, 4000, 0.03)
+    u, d = synth.select_markers(gen, 26, 48, keep_every=2, seed=6)
+    pu, pd = build_index(tmp_path, u, d, 26)
+    reads = synth.simulate_reads(gen, 15003, (26, rl), 0.01, 4, frac_random=0.1)
+    reads += synth.simulate_reads(gen, 5000, rl, 0.01, 5)                     # the batch maximum is exactly rl
+    b, o = synth.concat_reads(reads)
+    oi = oracle_lib.OracleIndex(pu, pd)
+    for mode in (cq.MODE_P, cq.MODE_SC):
+        ref = oi.query(b, o, len(gen), mode=mode, nthreads=8)
+        for nofix in ("0", "1"):
+            for hist in ("1000000", "0"):
+                monkeypatch.setenv("CAMMIQ_NO_FIXED_SHAPE", nofix)
+                monkeypatch.setenv("CAMMIQ_LDS_HIST_MAX", hist)
+                ix = cq.Index(pu, pd, device=0)
+                got = ix.query(b, o, len(gen), mode=mode)
+                li = ix.last_launch_info()
+                assert li["fixed_shape"] == (0 if nofix == "1" else 1), li
+                assert li["fixed_read_len"] == (0 if nofix == "1" else rl) and li["reads_per_subtile"] == 8
+                assert li["lds_hist"] == (1 if hist != "0" else 0)
+                assert_same(got, ref, f"rl={rl} nofix={nofix} hist={hist} mode={mode}", rcount=(mode == cq.MODE_P))
+                assert got["pairs"] == ref["pairs"]
+    # another hash length or another batch shape never takes it
+    monkeypatch.delenv("CAMMIQ_NO_FIXED_SHAPE")
+    ix = cq.Index(pu, pd, device=0)
+    ix.query(*synth.concat_reads(reads[:2000] + [b"ACGT" * 50]), len(gen))
+    assert ix.last_launch_info()["fixed_shape"] == 0

@@ -180,10 +180,23 @@ def test_pair_map_grows_instead_of_failing(tmp_path, monkeypatch):
     assert ix.count_pairs() == len(ref["pairs"])
     assert ix.fetch_pairs(1 << 12) == ref["pairs"]
     assert ix.count_pairs() == 0
+    # a failed query must not leak into the next one ("counters are OVERWRITTEN"): the pairs kept after
+    # CQ_ERR_LIMIT live only until the next query on the handle, which starts from an empty map
+    with pytest.raises(cq.CammiqError) as e:
+        ix.query(b, o, G, mode=cq.MODE_SC, pair_cap=8)
+    assert e.value.code == -9
+    got = ix.query(b, o, G, mode=cq.MODE_SC, pair_cap=1 << 12)
+    assert got["pairs"] == ref["pairs"], "pairs of a failed query were added onto the retry"
+    assert_same(got, ref, "retry after CQ_ERR_LIMIT", rcount=False)
     m = cq.Multi(pu, pd, [0, 0])                        # and with shards: every shard's map grows, maps are merged
     got = m.query(b, o, G, mode=cq.MODE_SC, pair_cap=1 << 12)
     assert got["pairs"] == ref["pairs"]
     assert_same(got, ref, "multi grown pair map", rcount=False)
+    with pytest.raises(cq.CammiqError) as e:            # same contract through the shards
+        m.query(b, o, G, mode=cq.MODE_SC, pair_cap=8)
+    assert e.value.code == -9
+    got = m.query(b, o, G, mode=cq.MODE_SC, pair_cap=1 << 12)
+    assert got["pairs"] == ref["pairs"]
 
 
 def test_comm_entry_points_world_size_one(tmp_path):

@@ -22,10 +22,20 @@ def test_oracle_matches_golden(name):
         got = ix.query(b, o, g["G"], mode=0, nthreads=threads)
         assert_same(got, g["exp"]["p"], f"{name} t={threads}")
         assert got["branch"] == g["exp"]["p"]["branch"]
+    # SURVEY 8(d)'s optimised CPU variant (per-thread counters merged after the loop, rcount by atomics):
+    # bit for bit the serial result, branch coverage included, in both modes
+    for threads in (1, 4, 7):
+        got = ix.query(b, o, g["G"], mode=0, nthreads=threads, variant="thread_local")
+        assert_same(got, g["exp"]["p"], f"{name} thread_local t={threads}")
+        assert got["branch"] == g["exp"]["p"]["branch"]
     sc = ix.query(b, o, g["G"], mode=1)
     assert_same(sc, g["exp"]["sc"], name + " sc", rcount=False)
     assert sorted([a, b_, c] for (a, b_), c in sc["pairs"].items()) == g["exp"]["sc"]["pairs"]
     assert int(sc["rcount_u"].sum()) == 0 and int(sc["rcount_d"].sum()) == 0
+    for variant in ("critical", "atomic", "thread_local"):
+        sc = ix.query(b, o, g["G"], mode=1, nthreads=5, variant=variant)
+        assert_same(sc, g["exp"]["sc"], f"{name} sc {variant}", rcount=False)
+        assert sorted([a, b_, c] for (a, b_), c in sc["pairs"].items()) == g["exp"]["sc"]["pairs"]
 
 
 def test_oracle_reproduces_survey_numbers():

@@ -8,7 +8,7 @@ tag=$1; shift
 out=$root/gpurun_out/pmc_$tag
 rm -rf "$out"; mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --pmc "$@" --output-format csv -d "$out" -- python3 "$root/bench.py" ${BENCH_ARGS:-} --steps 2 --warmup 1 --no-cpu-baseline --no-host-fed > "$out/bench.json" 2> "$out/err.log" || { echo "pass $tag ($*) failed:"; tail -5 "$out/err.log"; exit 0; }
+rocprofv3 --pmc "$@" --output-format csv -d "$out" -- python3 "$root/bench.py" ${BENCH_ARGS:-} --steps 2 --warmup 1 --no-cpu-baseline --no-host-fed > "$out/bench.json" 2> "$out/err.log" || { rc=$?; echo "pass $tag ($*) FAILED rc=$rc; last lines of err.log:"; tail -40 "$out/err.log"; exit $rc; }
 python3 - "$out" <<'PY'
 import csv,glob,sys,collections
 out=sys.argv[1]

@@ -5,6 +5,6 @@ for L in ${@:-100 150 250}; do
   for R in 8 4 auto; do
     if [ $R = auto ]; then unset CAMMIQ_FAST_R; else export CAMMIQ_FAST_R=$R; fi
     echo -n "len $L R $R: "
-    timeout -k 10 200 python tools/kexp.py --config 1 --steps 6 --extra "--read-len $L" tree | tail -1
+    python tools/kexp.py --timeout 200 --config 1 --steps 6 --extra "--read-len $L" tree | tail -1
   done
 done
