@@ -26,6 +26,12 @@ def _lib():
         L.cqs_free.argtypes = [C.c_void_p]
         L.cqs_write_index.restype = C.c_int
         L.cqs_write_index.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.cqs_write_index_with_sub.restype = C.c_int
+        L.cqs_write_index_with_sub.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
+                                               C.c_void_p, C.c_uint64, C.c_char_p, C.c_char_p, C.c_void_p, C.c_uint64,
+                                               C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.cqs_genome_bases.restype = C.c_int
+        L.cqs_genome_bases.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint32, C.c_void_p]
         L.cqs_make_reads.restype = C.c_int
         L.cqs_make_reads.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_double, C.c_double, C.c_void_p]
         L.cqs_make_reads_at.restype = C.c_int
@@ -43,6 +49,8 @@ class World:
         self.p = _Params(seed, n_genomes, genome_len, k, h, lmax, marker_every, block, frac_deep, pair_share)
         self.n_genomes = n_genomes
         self._h = _lib().cqs_create(C.byref(self.p))
+        if not self._h:
+            raise ValueError("cq_synth: n_genomes < 2^23, h <= k, h <= 31 and lmax <= 255 are required")
 
     def write_index(self, path_u: str, path_d: str | None = None):
         nu, nd = C.c_uint64(0), C.c_uint64(0)
@@ -51,6 +59,28 @@ class World:
         if rc != 0:
             raise IOError(f"cannot write {path_u}")
         return int(nu.value), int(nd.value)
+
+    def write_index_with_sub(self, path_u: str, path_d: str | None, hmers: np.ndarray, sub_u: str, sub_d: str | None):
+        """The full index AND a sub-index holding exactly its markers whose h-mer is in `hmers` (uint64, any order).
+        -> (n_u, n_d, ids_u, ids_d): ids_* = position of each sub-index leaf in the FULL index's decode order.
+        Reads all of whose windows (both strands) are in `hmers` classify identically against either index."""
+        hv = np.unique(np.ascontiguousarray(hmers, np.uint64))
+        ids = np.zeros(2 * len(hv) + 1, np.uint64)
+        nu, nd, su, sd = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        rc = _lib().cqs_write_index_with_sub(self._h, path_u.encode(), path_d.encode() if path_d else None, C.byref(nu),
+                                             C.byref(nd), hv.ctypes.data_as(C.c_void_p), len(hv), sub_u.encode(),
+                                             sub_d.encode() if sub_d else None, ids.ctypes.data_as(C.c_void_p), len(ids),
+                                             C.byref(su), C.byref(sd))
+        if rc != 0:
+            raise IOError(f"cannot write {path_u} / {sub_u} (rc {rc})")
+        su, sd = int(su.value), int(sd.value)
+        return int(nu.value), int(nd.value), ids[:su].copy(), ids[su:su + sd].copy()
+
+    def genome_bases(self, g: int, start: int, n: int) -> bytes:
+        out = np.empty(n, np.uint8)
+        if _lib().cqs_genome_bases(self._h, g, start, n, out.ctypes.data_as(C.c_void_p)) != 0:
+            raise ValueError("range outside the genome")
+        return out.tobytes()
 
     def reads(self, seed: int, n: int, length: int = 100, err: float = 0.01, frac_random: float = 0.1):
         """-> (bases uint8[n*length], offsets uint64[n+1])"""

@@ -312,9 +312,9 @@ int prepare_host(const char *path_u, const char *path_d, double budget, std::sha
         lt.lap("layout");
         // bucket/node arrays of the decode stage are no longer needed; leaves are (cq_index_leaves)
         for (int t = 0; t < 2; t++) {
-            std::vector<uint64_t>().swap(H->tab[t].bucket_key);
-            std::vector<uint32_t>().swap(H->tab[t].bucket_code);
-            std::vector<cq::Node>().swap(H->tab[t].nodes);
+            cq::RawVec<uint64_t>().swap(H->tab[t].bucket_key);
+            cq::RawVec<uint32_t>().swap(H->tab[t].bucket_code);
+            cq::RawVec<cq::Node>().swap(H->tab[t].nodes);
         }
         if (stamped) { (void)cq::save_image(cache_file, stamp, kpb_override, H->tab, H->img); lt.lap("image cache write"); }
     } catch (const std::bad_alloc &) {
@@ -741,9 +741,23 @@ int classify_range(cq_index *ix, int mode, const Feed &f, uint64_t lo, uint64_t 
     uint64_t c = 0;
     // inside the loop a failed HIP call ends the loop instead of returning: copies from the caller's memory may be in flight
 #define CQ_HIPB(call) if (hipError_t e_ = (call)) { rc = fail(CQ_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); break; } else (void)0
-    for (uint64_t c0 = lo; c0 < hi && rc == CQ_OK; c0 += kChunk, c++) {
+    // Chunk schedule.  The first chunk's copy and the last chunk's kernel have nothing to hide behind (~1 ms each at
+    // 2 M reads), so long inputs ramp: 1/4, 1/2 chunk at either end, full chunks between (same reads, same
+    // order, same results; CAMMIQ_CHUNK_RAMP=0 turns it off for A/B timing).
+    std::vector<uint64_t> sched;
+    {
+        static const bool ramp_on = !(getenv("CAMMIQ_CHUNK_RAMP") && atoi(getenv("CAMMIQ_CHUNK_RAMP")) == 0);
+        uint64_t left = hi - lo;
+        const bool ramp = ramp_on && kChunk >= 4096 && left >= 6 * kChunk;
+        if (ramp) { sched.push_back(kChunk / 4); sched.push_back(kChunk / 2); left -= kChunk / 4 + kChunk / 2; }
+        const uint64_t tail = ramp ? kChunk / 2 + kChunk / 4 : 0;
+        while (left > tail) { const uint64_t n = std::min(kChunk, left - tail); sched.push_back(n); left -= n; }
+        if (ramp) { sched.push_back(kChunk / 2); sched.push_back(kChunk / 4); }
+    }
+    uint64_t c0 = lo;
+    for (size_t ci = 0; ci < sched.size() && rc == CQ_OK; c0 += sched[ci], ci++, c++) {
         cq_index::Slot &sl = ix->slot[c % 3];
-        const uint64_t n = std::min(kChunk, hi - c0);
+        const uint64_t n = sched[ci];
         uint64_t max_len = f.max_len;
         uint32_t sw = f.sw;
         if (ascii) {   // longest read of the chunk (sizes the rows): a few threads, one would take ~1 ms per 2 M reads
@@ -1177,23 +1191,34 @@ int multi_query(cq_multi *m, int mode, const Feed &f, uint64_t n_reads, uint32_t
                                          rc_on ? nl : 0, dst->s_comp));
             CQ_HIP(hipStreamSynchronize(dst->s_comp));
         }
-        // ---- the exchange step: one all-reduce(sum) of the counter block and of rcount over the devices
+        // ---- the exchange step: one sum of the counter block and of rcount over the devices.  Only the host reads
+        //      the totals, and it reads device 0's copy: a reduce to that root moves (P-1)/P of the bytes once, where
+        //      the all-reduce moves them twice (SURVEY 5 suggests exactly this; CAMMIQ_MULTI_ALLREDUCE=1 restores the
+        //      all-reduce for A/B timing on a multi-GPU node).  cq_counts_allreduce -- one process per GPU, every
+        //      rank wants the totals -- stays an all-reduce.
+        static const bool all_reduce = getenv("CAMMIQ_MULTI_ALLREDUCE") && atoi(getenv("CAMMIQ_MULTI_ALLREDUCE")) != 0;
         CQ_NCCL(ncclGroupStart());
         ncclResult_t bad = ncclSuccess;
         for (size_t k = 0; k < m->leaders.size(); k++) {
             cq_index *ix = m->ix[m->leaders[k]];
-            ncclResult_t r = ncclAllReduce(ix->d_ctr, ix->d_ctr, cw, ncclUint64, ncclSum, m->comms[k], ix->s_comp);
-            if (r == ncclSuccess && rc_on) r = ncclAllReduce(ix->d_rc, ix->d_rc, nl, ncclUint32, ncclSum, m->comms[k], ix->s_comp);
+            ncclResult_t r;
+            if (all_reduce) {
+                r = ncclAllReduce(ix->d_ctr, ix->d_ctr, cw, ncclUint64, ncclSum, m->comms[k], ix->s_comp);
+                if (r == ncclSuccess && rc_on) r = ncclAllReduce(ix->d_rc, ix->d_rc, nl, ncclUint32, ncclSum, m->comms[k], ix->s_comp);
+            } else {   // root = communicator rank 0 = leaders[0] = m->ix[0]'s device (ncclCommInitAll numbers ranks in list order)
+                r = ncclReduce(ix->d_ctr, ix->d_ctr, cw, ncclUint64, ncclSum, 0, m->comms[k], ix->s_comp);
+                if (r == ncclSuccess && rc_on) r = ncclReduce(ix->d_rc, ix->d_rc, nl, ncclUint32, ncclSum, 0, m->comms[k], ix->s_comp);
+            }
             if (r != ncclSuccess) bad = r;
         }
         CQ_NCCL(ncclGroupEnd());
-        if (bad != ncclSuccess) return fail(CQ_ERR_COMM, std::string("ncclAllReduce: ") + ncclGetErrorString(bad));
+        if (bad != ncclSuccess) return fail(CQ_ERR_COMM, std::string("RCCL reduce of the counts: ") + ncclGetErrorString(bad));
         for (size_t k = 0; k < m->leaders.size(); k++) {
             cq_index *ix = m->ix[m->leaders[k]];
             CQ_HIP(hipSetDevice(ix->device));
             CQ_HIP(hipStreamSynchronize(ix->s_comp));
         }
-        // ---- every device now holds the totals; the host takes device 0's copy (query.cpp:251-258 hand-off)
+        // ---- device 0 now holds the totals; the host takes them from there (query.cpp:251-258 hand-off)
         uint64_t flags = 0;
         int rc = fetch_counts(m->ix[0], mode, n_genomes, out, &flags);
         if (rc != CQ_OK) return rc;

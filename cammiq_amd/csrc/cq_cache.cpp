@@ -23,7 +23,7 @@ namespace cq {
 
 namespace {
 
-constexpr uint32_t kLayoutRev = 10;   // bump whenever cq_device.h's table / trie / minimizer layout changes
+constexpr uint32_t kLayoutRev = 10 + 100 * (CQ_MAX_MINIMIZER - 16);   // experiment builds with another minimizer length never share a cache file with the product   // bump whenever cq_device.h's table / trie / minimizer layout changes
 
 struct Header {
     char magic[8];              // "CQIMG\0\0\0"

@@ -16,8 +16,12 @@
 // Unlike the reference (recursive, two heap allocations per node, ~100 B/node) this is a
 // single forward pass with an explicit stack that emits flat arrays: leaves in decode
 // order, one root code per bucket and 16-byte array-trie nodes for the (rare) deep keys.
+#include <algorithm>
+#include <atomic>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <thread>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <fcntl.h>
@@ -117,7 +121,187 @@ void make_empty_table(uint32_t hash_len, DecodedTable &out)
     out.nodes.push_back(Node{{0, 0, 0, 0}});
 }
 
+namespace {
+
+// ---- parallel decode --------------------------------------------------------------------------------------------
+// The two streams of a table can only be read front to back: where bucket i starts in the bit stream depends on the
+// shapes of all tries before it, and where it starts in the byte stream on the number of leaves before it.  A
+// first pass over the bit stream alone finds that out -- it walks the shapes without building anything (a '1'
+// followed by '0000' is a leaf, any other '1' opens four child slots) and notes, every `step` buckets, the bit
+// position and the bucket / leaf / node counts so far.  The chunks between two notes are then decoded by all cores
+// at once, each writing straight into its slice of the final arrays (whose exact sizes the first pass also gave):
+// ids are global from the start, nothing is relocated or copied.  The scan accepts exactly the well-formed
+// streams; anything else (truncation, a bucket without a root, a key longer than 255, a bad leaf record) sends the
+// file through the serial decoder below, which reports the first error the way it always did.
+struct Mark { size_t aux_pos; uint64_t buckets, leaves, nodes; };
+
+bool prescan(const uint8_t *ap, size_t nbits, size_t aux_start, const uint8_t *ip, size_t in, size_t rec, uint32_t h,
+             uint64_t step, std::vector<Mark> &marks)
+{
+    Bits aux{ap, nbits};
+    aux.pos = aux_start;
+    uint64_t nb = 0, nl = 0, nn = 0;
+    marks.clear();
+    for (;;) {
+        const uint64_t ipos = 8 * nb + rec * nl;
+        if (ipos + 8 > in) return false;
+        uint64_t hv = 0;
+        for (int k = 0; k < 8; k++) hv = (hv << 8) | ip[ipos + k];
+        if (nb % step == 0 || hv == CQ_EMPTY_KEY) marks.push_back(Mark{aux.pos, nb, nl, nn});
+        if (hv == CQ_EMPTY_KEY) return true;
+        if (aux.peek5() == 0x10u) { aux.pos += 5; nb++; nl++; continue; }   // "1 0000": the root is a leaf
+        if (aux.pos + 5 > nbits) return false;
+        if (aux.bit() != 1u) return false;
+        // depth bookkeeping: slots[d] = child slots of the open node at depth d still to be read
+        uint8_t slots[260];
+        uint32_t depth = 0;
+        slots[0] = 4;
+        nn++;   // the root is an inner node (it was not "1 0000")
+        for (;;) {
+            if (slots[depth] == 0) { if (depth == 0) break; depth--; continue; }
+            slots[depth]--;
+            if (aux.pos >= nbits) return false;
+            if (!aux.bit()) continue;
+            if (h + depth + 1 > 255) return false;
+            const size_t q = aux.pos;
+            if (q + 4 > nbits) return false;
+            // next four bits all zero: a leaf
+            uint32_t w = ((uint32_t)ap[q >> 3] << 8) | ((q >> 3) + 1 < ((nbits + 7) >> 3) ? ap[(q >> 3) + 1] : 0xFFu);
+            if (((w >> (12 - (q & 7))) & 15u) == 0) { aux.pos += 4; nl++; continue; }
+            nn++;
+            slots[++depth] = 4;
+        }
+        nb++;
+    }
+}
+
+}  // namespace
+
+static int decode_serial(const std::string &path, DecodedTable &out, std::string &err);
+
+// Chunk [m0, m1) of a well-formed table, into the final arrays at the offsets the scan found.  Same walk as
+// decode_serial with cursors instead of push_back.  Returns false on a leaf record the serial decoder rejects.
+static bool decode_chunk(const uint8_t *ap, size_t nbits, const uint8_t *ip, size_t in, size_t rec, uint32_t h, bool doubly,
+                         const Mark &m0, const Mark &m1, DecodedTable &out)
+{
+    Bits aux{ap, nbits};
+    aux.pos = m0.aux_pos;
+    Ints ints{ip, in};
+    ints.pos = 8 * m0.buckets + rec * m0.leaves;
+    uint64_t nl = m0.leaves, nn = 1 + m0.nodes;   // nodes[0] is the reserved dummy
+    cq_leaf *leaves = out.leaves.data();
+    Node *nodes = out.nodes.data();
+    auto read_leaf = [&](uint32_t trie_depth) -> bool {
+        cq_leaf lf;
+        memset(&lf, 0, sizeof lf);
+        lf.depth = (uint8_t)(h + trie_depth);
+        if (doubly) {
+            lf.refID1 = ints.u32(); lf.refID2 = ints.u32();
+            if (lf.refID1 == 0 || lf.refID2 == 0) return false;
+            lf.ucount1 = ints.u16(); lf.ucount2 = ints.u16();
+        } else {
+            lf.refID1 = ints.u32(); lf.ucount1 = ints.u16();
+            if (lf.refID1 == 0) return false;
+        }
+        leaves[nl++] = lf;
+        return true;
+    };
+    const uint64_t hv_limit = 1ull << (2 * h);
+    std::vector<Frame> stack;
+    stack.reserve(256);
+    for (uint64_t b = m0.buckets; b < m1.buckets; b++) {
+        const uint64_t hv = ints.u64();
+        if (hv >= hv_limit) return false;
+        if (aux.peek5() == 0x10u) {
+            aux.pos += 5;
+            if (!read_leaf(0)) return false;
+            out.bucket_key[b] = hv;
+            out.bucket_code[b] = CQ_LEAF_BIT | (uint32_t)(nl - 1);
+            continue;
+        }
+        (void)aux.bit();   // the root's '1'; not a leaf (that was the fast path), so an inner node
+        stack.clear();
+        nodes[nn] = Node{{0, 0, 0, 0}};
+        const uint32_t root_code = (uint32_t)nn;
+        stack.push_back(Frame{(uint32_t)nn++, 0, 0});
+        // Unlike the serial walk no tentative node is ever taken: a chunk owns exactly the node slots the scan counted
+        // for it, so a '1' is classified (leaf: next four bits zero) BEFORE a slot is used.
+        while (!stack.empty()) {
+            Frame &f = stack.back();
+            if (f.next == 4) { stack.pop_back(); continue; }
+            const uint32_t c = f.next++;
+            if (!aux.bit()) continue;
+            const size_t q = aux.pos;
+            const uint32_t w = ((uint32_t)ap[q >> 3] << 8) | ((q >> 3) + 1 < ((nbits + 7) >> 3) ? ap[(q >> 3) + 1] : 0xFFu);
+            if (((w >> (12 - (q & 7))) & 15u) == 0) {
+                aux.pos += 4;
+                if (!read_leaf((uint32_t)stack.size())) return false;
+                nodes[f.node].child[c] = CQ_LEAF_BIT | (uint32_t)(nl - 1);
+                continue;
+            }
+            const uint32_t parent = f.node;
+            nodes[nn] = Node{{0, 0, 0, 0}};
+            const uint32_t me = (uint32_t)nn++;
+            nodes[parent].child[c] = me;
+            stack.push_back(Frame{me, 0, 0});   // invalidates f
+        }
+        out.bucket_key[b] = hv;
+        out.bucket_code[b] = root_code;
+    }
+    return nl == m1.leaves && nn == 1 + m1.nodes && aux.pos == m1.aux_pos;
+}
+
 int decode_table(const std::string &path, DecodedTable &out, std::string &err)
+{
+    // CAMMIQ_DECODE_THREADS: 1 = always the serial decoder; CAMMIQ_DECODE_STEP: buckets per chunk (tests)
+    unsigned nt = std::max(1u, std::min(std::thread::hardware_concurrency(), 32u));
+    if (const char *v = getenv("CAMMIQ_DECODE_THREADS")) nt = (unsigned)std::max(1, atoi(v));
+    Mapped fi, fa;
+    if (nt > 1 && fi.open(path) && fa.open(path + ".aux") && fa.n >= 2 && (getenv("CAMMIQ_DECODE_STEP") || fi.n >= (64u << 20))) {
+        const uint32_t doubly = fa.p[0] >> 7, option = fa.p[0] & 127u, h = fa.p[1];
+        if (option == 64 && h >= 1 && h <= 31) {
+            const size_t rec = doubly ? 12 : 6;
+            uint64_t step = std::max<uint64_t>(1, fi.n / (8 + rec) / ((uint64_t)nt * 8));
+            if (const char *v = getenv("CAMMIQ_DECODE_STEP")) step = (uint64_t)std::max(1, atoi(v));
+            std::vector<Mark> marks;
+            if (prescan(fa.p, fa.n * 8, 16, fi.p, fi.n, rec, h, step, marks) && marks.back().leaves < 0x7FFFFFFFull &&
+                marks.back().nodes + 1 < 0x7FFFFFFFull) {
+                const Mark &end = marks.back();
+                out = DecodedTable();
+                out.doubly = doubly;
+                out.hash_len = h;
+                out.n_file_buckets = end.buckets;
+                // exact sizes, uninitialised storage (RawVec): first touched by the workers that fill it
+                out.leaves.resize(end.leaves); out.bucket_key.resize(end.buckets); out.bucket_code.resize(end.buckets);
+                out.nodes.resize(end.nodes + 1);
+                advise_huge(out.leaves.data(), end.leaves * sizeof(cq_leaf));
+                advise_huge(out.bucket_key.data(), end.buckets * sizeof(uint64_t));
+                advise_huge(out.bucket_code.data(), end.buckets * sizeof(uint32_t));
+                advise_huge(out.nodes.data(), (end.nodes + 1) * sizeof(Node));
+                out.nodes[0] = Node{{0, 0, 0, 0}};
+                const size_t nchunks = marks.size() - 1;
+                std::atomic<size_t> next{0};
+                std::atomic<bool> bad{false};
+                {
+                    std::vector<std::thread> th;
+                    for (unsigned t = 0; t < nt; t++)
+                        th.emplace_back([&] {
+                            for (;;) {
+                                const size_t c = next.fetch_add(1);
+                                if (c >= nchunks || bad.load()) break;
+                                if (!decode_chunk(fa.p, fa.n * 8, fi.p, fi.n, rec, h, doubly != 0, marks[c], marks[c + 1], out)) bad = true;
+                            }
+                        });
+                    for (auto &x : th) x.join();
+                }
+                if (!bad.load()) return CQ_OK;
+            }
+        }
+    }
+    return decode_serial(path, out, err);   // small files, and every file the scan did not accept: errors are reported here
+}
+
+static int decode_serial(const std::string &path, DecodedTable &out, std::string &err)
 {
     out = DecodedTable();
     Mapped fi, fa;

@@ -55,7 +55,10 @@
  * Random HBM accesses per read drop from 2(rl-h+1) to about 2(rl-h+1)/(h-m+2)  (150 -> ~12
  * for rl=100, h=26); lookups stay exact because every slot still holds the full key. */
 #ifndef CQ_MAX_MINIMIZER
-#define CQ_MAX_MINIMIZER 16
+#define CQ_MAX_MINIMIZER 16   /* <= 16: an m-mer is one 32-bit word and phi a bijection on it.  17..21 (experiment builds,
+                                 tools/build_full_variant.sh): m-mers are 64-bit, phi folds them to 32 bits -- no longer
+                                 a bijection, which the scheme does not need: only the minimum VALUE is used, and host
+                                 and device take it over the same m-mers.  Measured at 1.26e9 markers. */
 #endif
 
 CQ_HD uint32_t cq_minimizer_len(uint32_t h) { return h < CQ_MAX_MINIMIZER ? h : CQ_MAX_MINIMIZER; }
@@ -96,12 +99,37 @@ CQ_HD uint32_t cq_mmer_phi(uint32_t f, uint32_t m)
     return cq_phi32(f < r ? f : r);
 }
 
+/* The same for 16 < m <= 21: the canonical m-mer is up to 42 bits; its low word goes through phi's multiply, the
+ * high bits (< 2^10) through a second, 24-bit one (full rate on CDNA), then one xorshift. */
+CQ_HD uint32_t cq_phi_wide(uint64_t c)
+{
+    uint32_t x = (uint32_t)c * 0x9E3779B1u + (((uint32_t)(c >> 32) + 1u) & 0xFFFFFFu) * 0x85EBCBu;
+    x ^= x >> 15;
+    return x;
+}
+
+CQ_HD uint32_t cq_mmer_phi_wide(uint64_t f, uint32_t m)
+{
+    const uint64_t r = (~cq_rev2(f)) >> (64u - 2u * m);
+    return cq_phi_wide(f < r ? f : r);
+}
+
 /* Minimizer hash of an h-mer: min of cq_mmer_phi over its h-m+1 m-mers.  Strand symmetric:
  * the m-mers of the reverse complement are the reverse complements of these m-mers. */
 CQ_HD uint32_t cq_min_phi(uint64_t hmer, uint32_t h, uint32_t m)
 {
-    const uint32_t mask = m >= 16 ? 0xFFFFFFFFu : (1u << (2u * m)) - 1u;
     uint32_t best = 0xFFFFFFFFu;
+#if CQ_MAX_MINIMIZER > 16
+    if (m > 16) {
+        const uint64_t wmask = (1ull << (2u * m)) - 1ull;
+        for (uint32_t j = 0; j + m <= h; j++) {
+            const uint32_t p = cq_mmer_phi_wide((hmer >> (2u * (h - m - j))) & wmask, m);
+            best = p < best ? p : best;
+        }
+        return best;
+    }
+#endif
+    const uint32_t mask = m >= 16 ? 0xFFFFFFFFu : (1u << (2u * m)) - 1u;
     for (uint32_t j = 0; j + m <= h; j++) {
         const uint32_t p = cq_mmer_phi((uint32_t)(hmer >> (2u * (h - m - j))) & mask, m);
         best = p < best ? p : best;

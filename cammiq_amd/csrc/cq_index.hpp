@@ -14,12 +14,26 @@
 #include <cstdint>
 #include <memory>
 #include <string>
+#include <type_traits>
+#include <utility>
 #include <vector>
 
 #include "../../include/cammiq_hip.h"
 #include "cq_device.h"
 
 namespace cq {
+
+// std::vector whose resize() leaves trivially-constructible elements uninitialised: the multi-GB arrays of a decoded
+// table are sized once and first touched by the threads that fill them, not zeroed by the thread that sizes them.
+template <class T>
+struct DefaultInitAlloc : std::allocator<T> {
+    template <class U> struct rebind { using other = DefaultInitAlloc<U>; };
+    DefaultInitAlloc() = default;
+    template <class U> DefaultInitAlloc(const DefaultInitAlloc<U> &) {}
+    template <class U> void construct(U *p) noexcept(std::is_nothrow_default_constructible<U>::value) { ::new ((void *)p) U; }
+    template <class U, class... A> void construct(U *p, A &&...a) { ::new ((void *)p) U(std::forward<A>(a)...); }
+};
+template <class T> using RawVec = std::vector<T, DefaultInitAlloc<T>>;
 
 // A trie reference ("code"): 0 = absent, CQ_LEAF_BIT|leaf id = leaf, otherwise node index (>=1).
 struct Node { uint32_t child[4]; };  // A,C,G,T -- one 16-byte load per level on the GPU
@@ -28,10 +42,10 @@ struct DecodedTable {
     uint32_t hash_len = 0;
     uint32_t doubly = 0;
     uint64_t n_file_buckets = 0;
-    std::vector<cq_leaf> leaves;        // decode order (== map_sp fill order)
-    std::vector<uint64_t> bucket_key;   // hv of each bucket, file order
-    std::vector<uint32_t> bucket_code;  // root code of each bucket (table-local ids)
-    std::vector<Node> nodes;            // nodes[0] is a reserved dummy
+    RawVec<cq_leaf> leaves;        // decode order (== map_sp fill order)
+    RawVec<uint64_t> bucket_key;   // hv of each bucket, file order
+    RawVec<uint32_t> bucket_code;  // root code of each bucket (table-local ids)
+    RawVec<Node> nodes;            // nodes[0] is a reserved dummy
 };
 
 // The table image on the host: an uninitialised uint32 array, first touched by all cores at once.  From 32 MB on it

@@ -449,6 +449,7 @@ classify_kernel(DevIndex ix, QueryArgs a)
     static_assert((H == 0) == (RL == 0) && (H == 0 || (H >= 5 && H <= 31 && RL >= H && RL <= 255)), "H and RL are fixed together");
     constexpr bool FX = H != 0;
     constexpr uint32_t cM = H < CQ_MAX_MINIMIZER ? H : CQ_MAX_MINIMIZER, cW = FX ? RL - H + 1 : 0, cP = cW + (H - cM);
+    constexpr uint32_t cN = H - cM + 1;   // m-mers per window
     extern __shared__ __align__(16) uint32_t smem[];
     const uint32_t sw = FX ? (uint32_t)(RL + 15) / 16 : a.stride_words, swp = sw | 1u;
     const uint32_t G1 = a.n_genomes + 1;
@@ -572,6 +573,18 @@ classify_kernel(DevIndex ix, QueryArgs a)
                 // all kPrePos positions of the group are hashed and stored, valid or not (a row of phi holds whole
                 // groups): positions past len - m get the hash of whatever follows the read and are never read by a
                 // valid window -- no per-position branch
+#if CQ_MAX_MINIMIZER > 16
+                if (m > 16) {   // experiment builds: 64-bit m-mers (cq_device.h)
+                    const uint64_t wmask = (1ull << (2u * m)) - 1ull;
+#pragma unroll
+                    for (uint32_t k = 0; k < kPrePos; k++) {
+                        const uint64_t f = (w64 << (2u * k)) >> (64u - 2u * m);
+                        const uint64_t r = (rc64 >> (2u * k)) & wmask;
+                        dst[k] = cq_phi_wide(f < r ? f : r);
+                    }
+                    continue;
+                }
+#endif
 #pragma unroll
                 for (uint32_t k = 0; k < kPrePos; k++) {
                     const uint32_t f = (uint32_t)((w64 << (2u * k)) >> (64u - 2u * m));
@@ -657,6 +670,24 @@ classify_kernel(DevIndex ix, QueryArgs a)
                     for (uint32_t k = 1; k < KW; k++) {
                         pre = min(pre, v[k + 10]);
                         mp[k] = min(suf[k < 11 ? k : 10], pre);
+                    }
+                } else if (FX && cN >= KW) {
+                    // any fixed nphi >= KW (minimizer-length experiments): every window contains m-mer cN-1, so
+                    // window k = min(suffix minimum of v[k..cN-1], prefix minimum of v[cN-1..k+cN-1])
+                    constexpr uint32_t N = FX ? (cN >= KW ? cN : KW) : KW;
+                    uint32_t v[KW + N - 1];
+#pragma unroll
+                    for (uint32_t i = 0; i < KW + N - 1; i++) v[i] = ph[i];
+                    uint32_t suf[N];
+                    suf[N - 1] = v[N - 1];
+#pragma unroll
+                    for (int i = (int)N - 2; i >= 0; i--) suf[i] = min(v[i], suf[i + 1]);
+                    uint32_t pre = v[N - 1];
+                    mp[0] = suf[0];
+#pragma unroll
+                    for (uint32_t k = 1; k < KW; k++) {
+                        pre = min(pre, v[k + N - 1]);
+                        mp[k] = min(suf[k], pre);
                     }
                 } else {
 #pragma unroll

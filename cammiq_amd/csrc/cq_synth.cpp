@@ -201,6 +201,74 @@ inline void be(uint8_t *&o, uint64_t v, int nbytes)
 
 }  // namespace
 
+// Steps 3 + 4 of cqs_write_index for one table: `part` = kParts lists of markers in file order.
+static bool emit_table(const Params &p, int table, const std::vector<std::vector<Marker>> &part, const std::string &path,
+                       uint64_t &n_leaves_out)
+{
+    const size_t rec = table ? 12 : 6;
+    std::vector<uint64_t> nbits(kParts, 0), nbytes(kParts, 0);
+    thread_pool(kParts, [&](size_t q, unsigned) {
+        uint64_t bits = 0;
+        for (const Marker &m : part[q]) bits += 5u + 4u * (m.len() - p.h);   // inner level: '1' + 4 child slots; leaf: '1 0000'
+        nbits[q] = bits;
+        nbytes[q] = (uint64_t)part[q].size() * (8 + rec);
+    });
+    // ---- 3. offsets.  aux: 16 header bits, the partitions' bits, 72 one-bits, the final partial byte dropped
+    //         (binaryio.cpp:115-118 as the reference's writer leaves it); ints: records, END64, 0xFFFF
+    std::vector<uint64_t> bit0(kParts + 1), byte0(kParts + 1);
+    bit0[0] = 16; byte0[0] = 0;
+    uint64_t n_leaves = 0;
+    for (unsigned q = 0; q < kParts; q++) {
+        bit0[q + 1] = bit0[q] + nbits[q];
+        byte0[q + 1] = byte0[q] + nbytes[q];
+        n_leaves += part[q].size();
+    }
+    const uint64_t aux_bytes = (bit0[kParts] + 72) / 8, int_bytes = byte0[kParts] + 10;
+    OutMap fi, fa;
+    if (!fi.open(path, int_bytes) || !fa.open(path + ".aux", aux_bytes)) return false;
+    // ---- 4. emit in place.  A partition's bit range shares its first and last byte with its neighbours: those
+    //         two bytes are OR-ed in afterwards, everything between is written by the partition's worker alone.
+    std::vector<uint64_t> edge_off(2 * kParts, ~0ull);
+    std::vector<uint8_t> edge_val(2 * kParts, 0);
+    thread_pool(kParts, [&](size_t q, unsigned) {
+        const std::vector<Marker> &all = part[q];
+        uint8_t *o = fi.p + byte0[q];
+        const uint64_t b_lo = bit0[q], b_hi = bit0[q + 1];
+        const uint64_t first = b_lo / 8, last = b_hi ? (b_hi - 1) / 8 : 0;
+        std::vector<uint8_t> loc(b_hi > b_lo ? (size_t)(last - first + 1) : 0, 0);
+        uint64_t bp = b_lo - first * 8;   // bit cursor within loc
+        auto put = [&](uint32_t bit) { if (bit) loc[bp >> 3] |= (uint8_t)(0x80u >> (bp & 7)); bp++; };
+        uint8_t syms[256];
+        for (const Marker &m : all) {
+            be(o, m.hv, 8);
+            const uint32_t depth = m.len() - p.h;
+            if (depth) deep_symbols(p, m, syms);
+            // single-path trie below the bucket root, pre-order: per inner level '1', then '0' for the child slots
+            // before the path symbol; the leaf is '1 0000'; the slots after the path symbol close level by level
+            for (uint32_t d = 0; d < depth; d++) { put(1); for (uint32_t c = 0; c < syms[d]; c++) put(0); }
+            put(1); put(0); put(0); put(0); put(0);
+            for (uint32_t d = depth; d-- > 0;) for (uint32_t c = syms[d]; c < 3; c++) put(0);
+            const uint32_t g = m.genome();
+            if (table) { be(o, g + 1, 4); be(o, g + 2, 4); be(o, 1, 2); be(o, 1, 2); }
+            else { be(o, g + 1, 4); be(o, 1, 2); }
+        }
+        if (loc.empty()) return;
+        if (loc.size() > 2) memcpy(fa.p + first + 1, loc.data() + 1, loc.size() - 2);
+        edge_off[2 * q] = first; edge_val[2 * q] = loc[0];
+        if (loc.size() > 1) { edge_off[2 * q + 1] = last; edge_val[2 * q + 1] = loc.back(); }
+    });
+    fa.p[0] = (uint8_t)((table ? 0x80u : 0u) | 64u);
+    fa.p[1] = (uint8_t)p.h;
+    for (size_t e = 0; e < edge_off.size(); e++)
+        if (edge_off[e] != ~0ull && edge_off[e] < aux_bytes) fa.p[edge_off[e]] |= edge_val[e];
+    for (uint64_t b = bit0[kParts]; b < aux_bytes * 8; b++) fa.p[b >> 3] |= (uint8_t)(0x80u >> (b & 7));
+    uint8_t *o = fi.p + byte0[kParts];
+    be(o, 0xFFFFFFFFFFFFFFFFull, 8);
+    be(o, 0xFFFF, 2);
+    n_leaves_out = n_leaves;
+    return true;
+}
+
 extern "C" {
 
 struct cqs_params {
@@ -236,8 +304,35 @@ int cqs_genome_bases(void *hh, uint32_t g, uint64_t start, uint32_t n, uint8_t *
     return 0;
 }
 
+/* A second, much smaller index beside the full one: exactly the markers of the full index whose h-mer is in the
+ * sorted set hv[0..n_hv), in the full index's file order, plus the position of each in the full index's decode
+ * order (ids: sub_n[0] positions of the unique table, then sub_n[1] of the doubly-unique one).  A lookup of an
+ * h-mer of the set gives the same answer in both indices (find64_p starts with map64.find(h-mer),
+ * hashtrie.cpp:350-352, and both hold the same bucket for it), so reads whose every window is in the set classify
+ * identically against either: an oracle that cannot hold 10^9 markers checks a slice of reads against the
+ * sub-index and maps rcount through ids. */
+struct SubSpec { const uint64_t *hv; uint64_t n_hv; const char *path_u, *path_d; uint64_t *ids; uint64_t ids_cap; uint64_t n[2]; };
+
+static int write_index_impl(void *hh, const char *path_u, const char *path_d, uint64_t *n_leaves_u, uint64_t *n_leaves_d, SubSpec *sub);
+
 /* Writes index_u (and index_d when path_d != NULL and pair_share > 0).  Returns 0. */
 int cqs_write_index(void *hh, const char *path_u, const char *path_d, uint64_t *n_leaves_u, uint64_t *n_leaves_d)
+{
+    return write_index_impl(hh, path_u, path_d, n_leaves_u, n_leaves_d, nullptr);
+}
+
+int cqs_write_index_with_sub(void *hh, const char *path_u, const char *path_d, uint64_t *n_leaves_u, uint64_t *n_leaves_d,
+                             const uint64_t *hv_sorted, uint64_t n_hv, const char *sub_path_u, const char *sub_path_d,
+                             uint64_t *ids, uint64_t ids_cap, uint64_t *sub_n_u, uint64_t *sub_n_d)
+{
+    SubSpec sub{hv_sorted, n_hv, sub_path_u, sub_path_d, ids, ids_cap, {0, 0}};
+    const int rc = write_index_impl(hh, path_u, path_d, n_leaves_u, n_leaves_d, &sub);
+    if (sub_n_u) *sub_n_u = sub.n[0];
+    if (sub_n_d) *sub_n_d = sub.n[1];
+    return rc;
+}
+
+static int write_index_impl(void *hh, const char *path_u, const char *path_d, uint64_t *n_leaves_u, uint64_t *n_leaves_d, SubSpec *sub)
 {
     World &w = *(World *)hh;
     const Params &p = w.p;
@@ -299,8 +394,6 @@ int cqs_write_index(void *hh, const char *path_u, const char *path_d, uint64_t *
         // ---- 2. per partition: gather the workers' bins, sort by order_key, drop every h-mer that occurs more than once
         //         (one key per bucket: two keys with one h-mer prefix would need a branching trie)
         std::vector<std::vector<Marker>> part(kParts);
-        std::vector<uint64_t> nbits(kParts, 0), nbytes(kParts, 0);
-        const size_t rec = table ? 12 : 6;
         thread_pool(kParts, [&](size_t q, unsigned) {
             std::vector<Marker> &all = part[q];
             size_t tot = 0;
@@ -323,65 +416,35 @@ int cqs_write_index(void *hh, const char *path_u, const char *path_d, uint64_t *
                 i = j;
             }
             all.resize(wr);
-            uint64_t bits = 0;
-            for (const Marker &m : all) bits += 5u + 4u * (m.len() - p.h);   // inner level: '1' + 4 child slots; leaf: '1 0000'
-            nbits[q] = bits;
-            nbytes[q] = (uint64_t)all.size() * (8 + rec);
         });
         lap(table ? "sort + dedupe (d)" : "sort + dedupe (u)");
-        // ---- 3. offsets.  aux: 16 header bits, the partitions' bits, 72 one-bits, the final partial byte dropped
-        //         (binaryio.cpp:115-118 as the reference's writer leaves it); ints: records, END64, 0xFFFF
-        std::vector<uint64_t> bit0(kParts + 1), byte0(kParts + 1);
-        bit0[0] = 16; byte0[0] = 0;
         uint64_t n_leaves = 0;
-        for (unsigned q = 0; q < kParts; q++) {
-            bit0[q + 1] = bit0[q] + nbits[q];
-            byte0[q + 1] = byte0[q] + nbytes[q];
-            n_leaves += part[q].size();
+        if (!emit_table(p, table, part, table ? path_d : path_u, n_leaves)) return -1;
+        if (sub) {
+            // the sub-index: markers whose h-mer is in the set (a 2^27-bit filter in front of the binary search)
+            std::vector<uint64_t> filt(1u << 21, 0);
+            for (uint64_t i = 0; i < sub->n_hv; i++) { const uint64_t k = order_key(sub->hv[i]) >> 37; filt[k >> 6] |= 1ull << (k & 63); }
+            std::vector<std::vector<Marker>> spart(kParts);
+            std::vector<std::vector<uint64_t>> spos(kParts);
+            std::vector<uint64_t> base(kParts + 1, 0);
+            for (unsigned q = 0; q < kParts; q++) base[q + 1] = base[q] + part[q].size();
+            thread_pool(kParts, [&](size_t q, unsigned) {
+                for (size_t i = 0; i < part[q].size(); i++) {
+                    const uint64_t hv = part[q][i].hv, k = order_key(hv) >> 37;
+                    if (!((filt[k >> 6] >> (k & 63)) & 1u)) continue;
+                    if (!std::binary_search(sub->hv, sub->hv + sub->n_hv, hv)) continue;
+                    spart[q].push_back(part[q][i]);
+                    spos[q].push_back(base[q] + i);   // one leaf per bucket: position in file order == leaf id in decode order
+                }
+            });
+            uint64_t ns = 0;
+            if (!emit_table(p, table, spart, table ? sub->path_d : sub->path_u, ns)) return -1;
+            uint64_t at = table ? sub->n[0] : 0;
+            for (unsigned q = 0; q < kParts; q++)
+                for (uint64_t v : spos[q]) { if (at < sub->ids_cap) sub->ids[at] = v; at++; }
+            sub->n[table] = ns;
+            if (at > sub->ids_cap) return -2;
         }
-        const uint64_t aux_bytes = (bit0[kParts] + 72) / 8, int_bytes = byte0[kParts] + 10;
-        const std::string path = table ? path_d : path_u;
-        OutMap fi, fa;
-        if (!fi.open(path, int_bytes) || !fa.open(path + ".aux", aux_bytes)) return -1;
-        // ---- 4. emit in place.  A partition's bit range shares its first and last byte with its neighbours: those
-        //         two bytes are OR-ed in afterwards, everything between is written by the partition's worker alone.
-        std::vector<uint64_t> edge_off(2 * kParts, ~0ull);
-        std::vector<uint8_t> edge_val(2 * kParts, 0);
-        thread_pool(kParts, [&](size_t q, unsigned) {
-            const std::vector<Marker> &all = part[q];
-            uint8_t *o = fi.p + byte0[q];
-            const uint64_t b_lo = bit0[q], b_hi = bit0[q + 1];
-            const uint64_t first = b_lo / 8, last = b_hi ? (b_hi - 1) / 8 : 0;
-            std::vector<uint8_t> loc(b_hi > b_lo ? (size_t)(last - first + 1) : 0, 0);
-            uint64_t bp = b_lo - first * 8;   // bit cursor within loc
-            auto put = [&](uint32_t bit) { if (bit) loc[bp >> 3] |= (uint8_t)(0x80u >> (bp & 7)); bp++; };
-            uint8_t syms[256];
-            for (const Marker &m : all) {
-                be(o, m.hv, 8);
-                const uint32_t depth = m.len() - p.h;
-                if (depth) deep_symbols(p, m, syms);
-                // single-path trie below the bucket root, pre-order: per inner level '1', then '0' for the child slots
-                // before the path symbol; the leaf is '1 0000'; the slots after the path symbol close level by level
-                for (uint32_t d = 0; d < depth; d++) { put(1); for (uint32_t c = 0; c < syms[d]; c++) put(0); }
-                put(1); put(0); put(0); put(0); put(0);
-                for (uint32_t d = depth; d-- > 0;) for (uint32_t c = syms[d]; c < 3; c++) put(0);
-                const uint32_t g = m.genome();
-                if (table) { be(o, g + 1, 4); be(o, g + 2, 4); be(o, 1, 2); be(o, 1, 2); }
-                else { be(o, g + 1, 4); be(o, 1, 2); }
-            }
-            if (loc.empty()) return;
-            if (loc.size() > 2) memcpy(fa.p + first + 1, loc.data() + 1, loc.size() - 2);
-            edge_off[2 * q] = first; edge_val[2 * q] = loc[0];
-            if (loc.size() > 1) { edge_off[2 * q + 1] = last; edge_val[2 * q + 1] = loc.back(); }
-        });
-        fa.p[0] = (uint8_t)((table ? 0x80u : 0u) | 64u);
-        fa.p[1] = (uint8_t)p.h;
-        for (size_t e = 0; e < edge_off.size(); e++)
-            if (edge_off[e] != ~0ull && edge_off[e] < aux_bytes) fa.p[edge_off[e]] |= edge_val[e];
-        for (uint64_t b = bit0[kParts]; b < aux_bytes * 8; b++) fa.p[b >> 3] |= (uint8_t)(0x80u >> (b & 7));
-        uint8_t *o = fi.p + byte0[kParts];
-        be(o, 0xFFFFFFFFFFFFFFFFull, 8);
-        be(o, 0xFFFF, 2);
         lap(table ? "emit (d)" : "emit (u)");
         if (table == 0 && n_leaves_u) *n_leaves_u = n_leaves;
         if (table == 1 && n_leaves_d) *n_leaves_d = n_leaves;

@@ -131,3 +131,35 @@ def test_inline_pair_limit_falls_back_silently(tmp_path):
         assert_same(got, ref, f"refIDs around 2^15, mode {mode}", rcount=(mode == 0))
         assert got["pairs"] == ref["pairs"]
     assert int(ref["cnt_d"][remap[9]]) > 0 and int(ref["cnt_d"][remap[1]]) > 0
+
+
+def test_configs4_index_at_size():
+    """configs[4]'s per-GPU shard with the index at the size this box can build -- 15 000 genomes x 3.45 Mbp at the
+    survey's marker density = 1.26e9 markers (81 GB of table, ~97 GB on the device) where the host has the ~170 GB the
+    build peaks at, proportionally shorter genomes where it has not (CAMMIQ_CFG4_GENOME_LEN pins a length) -- and
+    20 M x 150 bp reads in ONE launch.  tools/configs4.py does the work: property checks that hold at any size
+    (conservation, idempotence, halves and the eight cq_shard_range shards add up leaf by leaf, host-fed door ==
+    device door) and the oracle on a 100 k-read slice against the generator's sub-index (the full index's markers
+    whose h-mer occurs in the slice: tests/test_subindex.py)."""
+    import json
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import configs4
+    G = 15_000
+    L, avail, shm = configs4.size_for_this_box(G, 3_450_000)
+    if os.environ.get("CAMMIQ_CFG4_GENOME_LEN"):
+        L = int(os.environ["CAMMIQ_CFG4_GENOME_LEN"])
+    if L < 400_000:
+        pytest.skip(f"host memory ({avail / 1e9:.0f} GB available, {shm / 1e9:.0f} GB of /dev/shm) is too small for an index beyond the shape test's")
+    rec = configs4.run(G, L, 20_000_000, 150, log=lambda s: print(s, flush=True))
+    out = os.path.join(root, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    json.dump(rec, open(os.path.join(out, "cfg4_test_record.json"), "w"), indent=1)
+    bad = [k for k, v in rec["checks"].items() if v is False]
+    assert not bad, f"{bad} failed at {rec['leaves_u']} + {rec['leaves_d']} markers"
+    assert rec["checks"]["genomes_hit"] > 14_900
+    assert rec["leaves_u"] + rec["leaves_d"] > 0.9 * G * L * configs4.MARKERS_PER_GENOME_BASE
+    assert rec["outcome"]["slow_path_reads"] < 0.001 * rec["reads"]
+    assert rec["kernel_launch"]["fixed_shape"] == 1 and rec["kernel_launch"]["lds_hist"] == 0    # 15 000 genomes: global counters

@@ -218,16 +218,25 @@ def test_packer_fuzz_all_byte_values():
     assert sk == nbad
 
 
-def test_loader_survives_corrupted_files(tmp_path):
+@pytest.mark.parametrize("decoder", ["serial", "parallel"])
+def test_loader_survives_corrupted_files(tmp_path, monkeypatch, decoder):
     """Bit flips, truncations and garbage must come back as status codes (the reference asserts
-    or walks off its buffers); a file that still loads must decode like the oracle does."""
+    or walks off its buffers); a file that still loads must decode like the oracle does.  Both
+    decoders: the chunked one (scan + parallel chunks) hands every stream its scan does not accept to the
+    serial one, so the two must agree on what loads and on the status of what does not."""
     import random
+    if decoder == "parallel":
+        monkeypatch.setenv("CAMMIQ_DECODE_THREADS", "4")
+        monkeypatch.setenv("CAMMIQ_DECODE_STEP", "5")
+    else:
+        monkeypatch.setenv("CAMMIQ_DECODE_THREADS", "1")
     gen = synth.clade_genomes(3, 1, 3, 800, 0.05)
     u, d = synth.select_markers(gen, 12, 20, keep_every=2, seed=1)
     pu, pd = build_index(tmp_path, u, d, 10, "fz")
     good = {p: open(p, "rb").read() for p in (pu, pu + ".aux", pd, pd + ".aux")}
     rng = random.Random(7)
     loaded = failed = 0
+    outcome = []
     for trial in range(120):
         victim = rng.choice(list(good))
         data = bytearray(good[victim])
@@ -244,12 +253,50 @@ def test_loader_survives_corrupted_files(tmp_path):
             ix = cq.Index(pu, pd, device=-1)
             loaded += 1
             assert ix.n_leaves[0] >= 0 and ix.info.max_chain < 1000
+            outcome.append(("ok", tuple(ix.n_leaves), ix.info_dict()["n_trie_nodes"]))
             ix.close()
         except cq.CammiqError as e:
             failed += 1
             assert e.code in (-2, -3, -4, -9), e
+            outcome.append(("err", e.code))
         open(victim, "wb").write(good[victim])
     assert failed > 20 and loaded + failed == 120
+    _CORRUPTION_OUTCOMES[decoder] = outcome
+    if len(_CORRUPTION_OUTCOMES) == 2:
+        assert _CORRUPTION_OUTCOMES["serial"] == _CORRUPTION_OUTCOMES["parallel"]
+
+
+_CORRUPTION_OUTCOMES = {}
+
+
+@pytest.mark.parametrize("name", ["f_deep", "survey_F2", "f_flat"])
+def test_chunked_decoder_equals_serial_decoder(name, tmp_path, monkeypatch):
+    """cq_decode.cpp: a scan of the bit stream finds where every chunk of buckets starts (bit position, bucket / leaf /
+    node counts), the chunks are decoded by all cores straight into the final arrays.  The finished image --
+    leaves in decode order, table, trie nodes -- must be byte-identical to the serial decoder's for any chunking."""
+    import shutil
+    g = golden(name)
+    monkeypatch.setenv("CAMMIQ_IMAGE_CACHE", "1")
+    images = []
+    for threads, step in (("1", None), ("2", "1"), ("5", "7"), ("8", "1000"), ("3", "100000000")):
+        d = tmp_path / f"t{threads}_s{step}"
+        d.mkdir()
+        pu = str(d / "index_u.bin1")
+        pd = str(d / "index_d.bin2") if g["pd"] else None
+        for src, dst in ((g["pu"], pu), (g["pd"], pd)):
+            if src:
+                shutil.copy2(src, dst)
+                shutil.copy2(src + ".aux", dst + ".aux")
+        monkeypatch.setenv("CAMMIQ_DECODE_THREADS", threads)
+        if step:
+            monkeypatch.setenv("CAMMIQ_DECODE_STEP", step)
+        else:
+            monkeypatch.delenv("CAMMIQ_DECODE_STEP", raising=False)
+        ix = cq.Index(pu, pd, device=-1)
+        images.append((ix.info_dict(), open(pu + ".cqimg", "rb").read()))
+    for other in images[1:]:
+        assert other[0] == images[0][0]
+        assert other[1] == images[0][1], "chunked decode differs from the serial decode"
 
 
 def _snapshot(ix, probes):

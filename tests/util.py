@@ -40,3 +40,21 @@ def build_index(tmpdir, keys_u, keys_d, h, name="ix", seed=0):
     synth.write_index(pu, keys_u, h, False, order_seed=seed)
     synth.write_index(pd, keys_d, h, True, order_seed=seed + 1)
     return pu, pd
+
+
+def hmers_of_reads(bases: np.ndarray, n: int, rl: int, h: int) -> np.ndarray:
+    """Every h-mer (forward and reverse complement, 2h-bit packed as the reference's rolling hash packs it,
+    query.cpp:482-485) of n fixed-length ACGT reads: the set of keys map64.find can be asked for by these reads."""
+    lut = np.full(256, 255, np.uint8)
+    for i, c in enumerate(b"ACGT"):
+        lut[c] = i
+    codes = lut[np.ascontiguousarray(bases[:n * rl], np.uint8)].reshape(n, rl)
+    assert codes.max() < 4
+    out = []
+    for c in (codes, (3 - codes)[:, ::-1]):          # the read, then its reverse complement (getRC, query.cpp:447-450)
+        W = rl - h + 1
+        hv = np.zeros((n, W), np.uint64)
+        for j in range(h):
+            hv = (hv << np.uint64(2)) | c[:, j:j + W].astype(np.uint64)
+        out.append(hv.ravel())
+    return np.unique(np.concatenate(out))

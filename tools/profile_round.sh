@@ -1,6 +1,12 @@
 #!/bin/bash
 # tools/profile_round.sh TAG [bench.py args...]  -- the rocprof evidence bench.py's roofline object cites
-# (run on the GPU box; TAG names the workload, e.g. "cfg2" for the default run, "cfg1" with `--config 1`):
+# (run on the GPU box; TAG names the workload, e.g. "cfg2" for the default run, "cfg1" with `--config 1`).
+# Everything comes from ONE lease, so that the un-profiled line, the --stats mean and the clock the chip held can
+# be compared (boxes of the pool differ by up to ~12 % in kernel time):
+#   0. the un-profiled bench line (HIP-event kernel ms)         -> gpurun_out/prof_TAG/bench_unprofiled.json
+#      + the in-kernel clock of a diagnostic -DCQ_STAMPS=1 build (variants/libcammiq_stamps.so, built here by
+#        tools/build_variant.sh stamps -DCQ_STAMPS=1): shader cycles / 100 MHz ticks over the waves' main
+#        loops (MI355X_MICROARCH.md, DVFS item 6)               -> gpurun_out/prof_TAG/clock.txt
 #   1. rocprofv3 --kernel-trace --stats of a bench run          -> gpurun_out/prof_TAG/kernel_stats.csv
 #   2. rocprofv3 --pmc FETCH_SIZE, then --pmc WRITE_SIZE (separate passes: FETCH_SIZE takes 3 of the 4 TCC
 #      slots, WRITE_SIZE 2 -- MI355X_MICROARCH.md "rocprofv3 PMC slots") -> gpurun_out/prof_TAG/traffic.json
@@ -13,6 +19,10 @@ tag=$1; shift
 out=$root/gpurun_out/prof_$tag
 rm -rf "$out"; mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
+python3 "$root/bench.py" "$@" --steps 6 --warmup 2 --no-cpu-baseline --no-host-fed > "$out/bench_unprofiled.json" 2> "$out/bench_unprofiled.err" || { tail -20 "$out/bench_unprofiled.err"; exit 1; }
+if [ -f "$root/variants/libcammiq_stamps.so" ]; then
+  CAMMIQ_LIB="$root/variants/libcammiq_stamps.so" CAMMIQ_STAMPS_FILE="$out/clock.txt" python3 "$root/bench.py" "$@" --steps 6 --warmup 2 --no-cpu-baseline --no-host-fed > "$out/bench_stamps.json" 2> "$out/bench_stamps.err" || tail -5 "$out/bench_stamps.err"
+fi
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -- python3 "$root/bench.py" "$@" --steps 6 --warmup 2 --no-cpu-baseline --no-host-fed > "$out/bench_under_rocprof.json" 2> "$out/trace.err"
 cp "$(ls "$out"/trace/*/*kernel_stats.csv | head -1)" "$out/kernel_stats.csv"
 for c in FETCH_SIZE WRITE_SIZE; do
@@ -40,6 +50,21 @@ res["row_stream_bytes"]=rows
 res["hbm_bytes_per_launch"]=(res["FETCH_SIZE_KB_per_launch"]+res["WRITE_SIZE_KB_per_launch"])*1024+0.5*rows
 res["workload_key"]=cfg["workload_key"]; res["table_GB"]=cfg["table_GB"]
 res["kernel_ms_under_stats"]=line["roofline"]["kernel_ms"]
+res["kernel"]=line["roofline"].get("kernel")
+# the --stats mean of the fast classify kernel itself (what a reader recomputes the fraction from)
+import os
+for r in csv.DictReader(open(out+"/kernel_stats.csv")):
+    if "classify_kernel" in r["Name"] and ("Lb0" in r["Name"] or "false" in r["Name"]):
+        res["kernel_ms_rocprof_stats"]=float(r["AverageNs"])/1e6; res["rocprof_stats_calls"]=int(r["Calls"]); res["rocprof_stats_name"]=r["Name"]
+up=out+"/bench_unprofiled.json"
+if os.path.exists(up):
+    try:
+        u=json.loads(open(up).read().strip().splitlines()[-1]); res["kernel_ms_unprofiled_same_lease"]=u["roofline"]["kernel_ms"]; res["value_unprofiled_same_lease"]=u["value"]
+    except Exception: pass
+ck=out+"/clock.txt"
+if os.path.exists(ck):
+    for l in open(ck):
+        if l.startswith("in_kernel_clock_MHz"): res["in_kernel_clock_MHz"]=float(l.split()[1])
 json.dump(res,open(out+"/traffic.json","w"),indent=1); print(json.dumps(res))
 PY
 mib=$(python3 -c "import json;print(int(json.load(open('$out/traffic.json'))['table_GB']*1e9/1048576))")
