@@ -29,13 +29,14 @@ class _Info(C.Structure):
                 ("device", C.c_int32), ("doubly_flag", C.c_uint32 * 2), ("n_leaves", C.c_uint64 * 2),
                 ("n_file_buckets", C.c_uint64 * 2), ("n_trie_nodes", C.c_uint64), ("n_keys", C.c_uint64),
                 ("n_table_buckets", C.c_uint64), ("n_overflowed", C.c_uint64), ("max_chain", C.c_uint32),
-                ("reserved_", C.c_uint32), ("device_bytes", C.c_uint64)]
+                ("reserved_", C.c_uint32), ("device_bytes", C.c_uint64), ("minimizer_len", C.c_uint32),
+                ("reserved2_", C.c_uint32)]
 
 
 class _LaunchInfo(C.Structure):
     _fields_ = [("reads_per_subtile", C.c_int32), ("hit_slots", C.c_int32), ("lds_hist", C.c_int32),
                 ("fixed_shape", C.c_int32), ("fixed_hash_len", C.c_int32), ("fixed_read_len", C.c_int32),
-                ("blocks_per_cu", C.c_int32), ("reserved", C.c_int32)]
+                ("blocks_per_cu", C.c_int32), ("minimizer_len", C.c_int32)]
 
 
 class _Counts(C.Structure):
@@ -242,7 +243,7 @@ class Index:
                     n_leaves=list(i.n_leaves), n_file_buckets=list(i.n_file_buckets),
                     n_trie_nodes=i.n_trie_nodes, n_keys=i.n_keys, n_table_buckets=i.n_table_buckets,
                     n_overflowed=i.n_overflowed, max_chain=i.max_chain, device_bytes=i.device_bytes,
-                    doubly_flag=list(i.doubly_flag))
+                    doubly_flag=list(i.doubly_flag), minimizer_len=i.minimizer_len)
 
     def leaves(self, table: int) -> np.ndarray:
         out = np.zeros(self.n_leaves[table], LEAF_DTYPE)
@@ -315,8 +316,8 @@ class Index:
         """Which instantiation of the classify kernel the most recent launch ran (cq_last_launch_info)."""
         li = _LaunchInfo()
         _check(lib().cq_last_launch_info(self._h, C.byref(li)))
-        d = {k: int(getattr(li, k)) for k, _ in _LaunchInfo._fields_ if k != "reserved"}
-        fx = f",{d['fixed_hash_len']},{d['fixed_read_len']}" if d["fixed_shape"] else ",0,0"
+        d = {k: int(getattr(li, k)) for k, _ in _LaunchInfo._fields_}
+        fx = f",{d['fixed_hash_len']},{d['fixed_read_len']},{d['minimizer_len']}" if d["fixed_shape"] else ",0,0,0"
         d["kernel"] = f"classify_kernel<{d['reads_per_subtile']},{d['hit_slots']},false{fx}>"
         return d
 

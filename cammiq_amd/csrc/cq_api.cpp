@@ -252,7 +252,7 @@ int upload(cq_index *ix)
     ix->dev.leaf_rids = (const uint2 *)ix->d_leaf_rids;
     ix->dev.n_buckets = (uint32_t)img.n_buckets;
     ix->dev.hash_len = img.hash_len;
-    ix->dev.minimizer_len = cq_minimizer_len(img.hash_len);
+    ix->dev.minimizer_len = img.minimizer_len;
     return CQ_OK;
 }
 
@@ -283,8 +283,10 @@ int prepare_host(const char *path_u, const char *path_d, double budget, std::sha
     const bool stamped = use_cache && cq::stamp_sources(path_u, have_d ? path_d : "", stamp);
     bool from_cache = false;
     const double kpb_override = getenv("CAMMIQ_KEYS_PER_BUCKET") ? atof(getenv("CAMMIQ_KEYS_PER_BUCKET")) : 0.0;
+    // minimizer length of the table: automatic by its size (cq_device.h), CAMMIQ_MINIMIZER_LEN overrides (tuning knob)
+    const uint32_t m_override = getenv("CAMMIQ_MINIMIZER_LEN") ? (uint32_t)std::max(0, atoi(getenv("CAMMIQ_MINIMIZER_LEN"))) : 0u;
     if (stamped)
-        from_cache = cq::load_image(cache_file, stamp, kpb_override, budget >= 1e29 ? ~0ull : (uint64_t)budget, H->tab, H->img);
+        from_cache = cq::load_image(cache_file, stamp, kpb_override, m_override, budget >= 1e29 ? ~0ull : (uint64_t)budget, H->tab, H->img);
     if (from_cache) lt.lap("image cache read");
     // The reference loads the two files on two pthreads (query.cpp:112-116); same here.
     int rc_u = CQ_OK, rc_d = CQ_OK;
@@ -307,7 +309,8 @@ int prepare_host(const char *path_u, const char *path_d, double budget, std::sha
         const double keys = (double)(H->tab[0].bucket_key.size() + H->tab[1].bucket_key.size());
         if (keys / kpb * 64.0 > budget) kpb = std::min(3.2, keys * 64.0 / budget);
         if (kpb_override > 0.0) kpb = kpb_override;
-        int rc = cq::build_image(H->tab[0], H->tab[1], kpb, H->img, err);
+        const uint32_t m_len = m_override ? cq_minimizer_len(H->tab[0].hash_len, std::min<uint32_t>(m_override, CQ_MAX_MINIMIZER)) : 0u;
+        int rc = cq::build_image(H->tab[0], H->tab[1], kpb, m_len, H->img, err);
         if (rc != CQ_OK) return fail(rc, err);
         lt.lap("layout");
         // bucket/node arrays of the decode stage are no longer needed; leaves are (cq_index_leaves)
@@ -316,7 +319,7 @@ int prepare_host(const char *path_u, const char *path_d, double budget, std::sha
             cq::RawVec<uint32_t>().swap(H->tab[t].bucket_code);
             cq::RawVec<cq::Node>().swap(H->tab[t].nodes);
         }
-        if (stamped) { (void)cq::save_image(cache_file, stamp, kpb_override, H->tab, H->img); lt.lap("image cache write"); }
+        if (stamped) { (void)cq::save_image(cache_file, stamp, kpb_override, m_override, H->tab, H->img); lt.lap("image cache write"); }
     } catch (const std::bad_alloc &) {
         return fail(CQ_ERR_NOMEM, "out of memory while loading the index");
     }
@@ -388,10 +391,10 @@ int cq_index_load(const char *path_u, const char *path_d, int device, cq_index *
         rc = upload(ix);
         lt.lap("upload");
         if (rc != CQ_OK) { release_device(ix); delete ix; return rc; }
+        warm_workspace(ix, &lt);            // before the host image goes back: its munmap and these allocations contend for the mmap lock
+        lt.lap("workspace (rest)");
         drop_host_image(*ix->H);
         lt.lap("release host image");
-        warm_workspace(ix, &lt);
-        lt.lap("workspace (rest)");
     }
     *out = ix;
     return CQ_OK;
@@ -418,6 +421,7 @@ int cq_index_get_info(const cq_index *ix, cq_index_info *info)
     info->max_chain = H.img.max_chain;
     info->device_bytes = ix->device_bytes;
     info->reserved_ = H.from_cache ? 1u : 0u;
+    info->minimizer_len = H.img.minimizer_len;
     return CQ_OK;
 }
 
@@ -520,7 +524,7 @@ int cq_last_launch_info(cq_index *ix, cq_launch_info *out)
     out->fixed_hash_len = l.fixed_h;
     out->fixed_read_len = l.fixed_read_len;
     out->blocks_per_cu = l.blocks_per_cu;
-    out->reserved = 0;
+    out->minimizer_len = l.minimizer_len;
     return CQ_OK;
 }
 

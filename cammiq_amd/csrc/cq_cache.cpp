@@ -23,13 +23,13 @@ namespace cq {
 
 namespace {
 
-constexpr uint32_t kLayoutRev = 10 + 100 * (CQ_MAX_MINIMIZER - 16);   // experiment builds with another minimizer length never share a cache file with the product   // bump whenever cq_device.h's table / trie / minimizer layout changes
+constexpr uint32_t kLayoutRev = 11;   // bump whenever cq_device.h's table / trie / minimizer layout changes
 
 struct Header {
     char magic[8];              // "CQIMG\0\0\0"
-    uint32_t layout_rev, slots_per_bucket, bucket_words, max_minimizer;
+    uint32_t layout_rev, slots_per_bucket, bucket_words, minimizer_len;   // minimizer_len: m of THIS image
     SourceStamp src;
-    uint32_t hash_len, doubly[2], max_chain, max_refid, pad_;
+    uint32_t hash_len, doubly[2], max_chain, max_refid, m_override;   // m_override: CAMMIQ_MINIMIZER_LEN the image was built with, 0 = automatic
     uint64_t n_file_buckets[2], n_leaves[2];
     uint64_t n_buckets, n_buckets_alloc, n_keys, n_overflowed, n_nodes, table_words;
     double kpb_override;        // CAMMIQ_KEYS_PER_BUCKET the image was built with, 0 = automatic
@@ -115,14 +115,14 @@ bool stamp_sources(const std::string &path_u, const std::string &path_d, SourceS
     return true;
 }
 
-bool save_image(const std::string &file, const SourceStamp &src, double kpb_override, const DecodedTable tab[2],
-                const FlatImage &img)
+bool save_image(const std::string &file, const SourceStamp &src, double kpb_override, uint32_t m_override,
+                const DecodedTable tab[2], const FlatImage &img)
 {
     Header h;
     memset(&h, 0, sizeof h);
     memcpy(h.magic, "CQIMG", 5);
     h.layout_rev = kLayoutRev; h.slots_per_bucket = CQ_SLOTS_PER_BUCKET; h.bucket_words = CQ_BUCKET_WORDS;
-    h.max_minimizer = CQ_MAX_MINIMIZER;
+    h.minimizer_len = img.minimizer_len; h.m_override = m_override;
     h.src = src;
     h.kpb_override = kpb_override;
     h.hash_len = img.hash_len; h.max_chain = img.max_chain; h.max_refid = img.max_refid;
@@ -147,15 +147,16 @@ bool save_image(const std::string &file, const SourceStamp &src, double kpb_over
     return ok;
 }
 
-bool load_image(const std::string &file, const SourceStamp &src, double kpb_override, uint64_t max_table_bytes,
-                DecodedTable tab[2], FlatImage &img)
+bool load_image(const std::string &file, const SourceStamp &src, double kpb_override, uint32_t m_override,
+                uint64_t max_table_bytes, DecodedTable tab[2], FlatImage &img)
 {
     int fd = ::open(file.c_str(), O_RDONLY);
     if (fd < 0) return false;
     Header h;
     bool ok = pread_all(fd, &h, sizeof h, 0) && memcmp(h.magic, "CQIMG\0\0\0", 8) == 0 && h.layout_rev == kLayoutRev &&
               h.slots_per_bucket == CQ_SLOTS_PER_BUCKET && h.bucket_words == CQ_BUCKET_WORDS &&
-              h.max_minimizer == CQ_MAX_MINIMIZER && memcmp(&h.src, &src, sizeof src) == 0 && h.kpb_override == kpb_override &&
+              h.minimizer_len >= 1 && h.minimizer_len <= CQ_MAX_MINIMIZER && h.minimizer_len <= h.hash_len && h.m_override == m_override &&
+              memcmp(&h.src, &src, sizeof src) == 0 && h.kpb_override == kpb_override &&
               h.table_words == h.n_buckets_alloc * CQ_BUCKET_WORDS && h.n_nodes >= 1 &&
               h.table_words * sizeof(uint32_t) <= max_table_bytes && h.hash_len >= 1 && h.hash_len <= 31;
     struct stat st;
@@ -184,7 +185,7 @@ bool load_image(const std::string &file, const SourceStamp &src, double kpb_over
     }
     ::close(fd);
     if (!ok) return false;
-    img.hash_len = h.hash_len; img.max_chain = h.max_chain; img.max_refid = h.max_refid;
+    img.hash_len = h.hash_len; img.minimizer_len = h.minimizer_len; img.max_chain = h.max_chain; img.max_refid = h.max_refid;
     img.n_leaves[0] = h.n_leaves[0]; img.n_leaves[1] = h.n_leaves[1];
     img.n_buckets = h.n_buckets; img.n_buckets_alloc = h.n_buckets_alloc; img.n_keys = h.n_keys;
     img.n_overflowed = h.n_overflowed;

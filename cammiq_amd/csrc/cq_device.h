@@ -47,21 +47,37 @@
  * A window's forward h-mer F and its reverse complement R are BOTH looked up (the reference
  * scans both strands, query.cpp:480-527), and neighbouring windows overlap in h-1 bases.
  * Keys are therefore not placed by hash(key) but by hash(minimizer(key)): the canonical
- * m-mer (m = min(h, 16)) that minimises a bijective 32-bit hash phi over all m-mers of the
+ * m-mer (m = min(h, 16), or 18 for large tables: below) that minimises a 32-bit hash phi over all m-mers of the
  * key and of its reverse complement (only the minimum phi itself is used).  Consequences:
  *   * F and R have the same minimizer -> ONE bucket chain serves both strand lookups;
  *   * consecutive windows share their minimizer for ~(h-m+2)/2 positions -> adjacent lanes
  *     read the SAME 64-byte bucket and the memory system serves them with one HBM access.
  * Random HBM accesses per read drop from 2(rl-h+1) to about 2(rl-h+1)/(h-m+2)  (150 -> ~12
  * for rl=100, h=26); lookups stay exact because every slot still holds the full key. */
-#ifndef CQ_MAX_MINIMIZER
-#define CQ_MAX_MINIMIZER 16   /* <= 16: an m-mer is one 32-bit word and phi a bijection on it.  17..21 (experiment builds,
-                                 tools/build_full_variant.sh): m-mers are 64-bit, phi folds them to 32 bits -- no longer
-                                 a bijection, which the scheme does not need: only the minimum VALUE is used, and host
-                                 and device take it over the same m-mers.  Measured at 1.26e9 markers. */
-#endif
+/* The minimizer length is a property of the INDEX, chosen when it is laid out (cq_choose_minimizer_len):
+ *   m = 16  an m-mer is one 32-bit word and phi a bijection on it; windows share their minimizer for ~(h-m+2)/2 = 6
+ *           positions (h = 26).  The right choice up to a few 10^8 keys.
+ *   m = 18  (17..21 possible) for large tables.  The bucket address is a function of the minimizer's 32-bit phi
+ *           value, and the minima of the keys concentrate on the SMALL values: N keys with w = h-m+1 m-mers each put
+ *           ~N w / 2^32 keys on every small value.  At 1.26e9 keys and m = 16 (w = 11) that is 3.2 keys per address
+ *           where the table has 4 slots: 9.6 % of the buckets overflowed, chains up to 9, and the kernel took
+ *           39.0 ms per 20 M x 150-bp reads; m = 17: 4.6 %, 21.3 ms; m = 18 (w = 9; 36-bit m-mers folded to 32 bits by
+ *           cq_phi_wide -- not a bijection, which the scheme does not need: only the minimum VALUE is used, and host
+ *           and device take it over the same m-mers): 3.7 %, 20.0 ms (profiles/r03_cfg4_*).  Shorter
+ *           runs (5 positions) are the price: on configs[2]'s 84 M keys m = 18 is slower than m = 16. */
+#define CQ_MAX_MINIMIZER 21               /* k + m <= 32 for the pre-pass's 11 positions per 64-bit piece */
+#define CQ_MINIMIZER_SMALL 16
+#define CQ_MINIMIZER_LARGE 18
+#define CQ_MINIMIZER_LARGE_FROM 250000000ull   /* keys.  Measured (kernel ms, m = 16 / 17 / 18): 84 M keys 21.0 / 22.2 / 23.8;
+                                                  420 M keys 18.2 / 16.8 / 16.9; 1.26e9 keys 39.0 / 21.3 / 20.0 (19: 20.6, 20: 21.2) */
 
-CQ_HD uint32_t cq_minimizer_len(uint32_t h) { return h < CQ_MAX_MINIMIZER ? h : CQ_MAX_MINIMIZER; }
+CQ_HD uint32_t cq_minimizer_len(uint32_t h, uint32_t want) { return h < want ? h : want; }
+
+/* The layout's choice for a table of n_keys keys (CAMMIQ_MINIMIZER_LEN overrides it on the host). */
+CQ_HD uint32_t cq_choose_minimizer_len(uint32_t h, uint64_t n_keys)
+{
+    return cq_minimizer_len(h, n_keys >= CQ_MINIMIZER_LARGE_FROM ? CQ_MINIMIZER_LARGE : CQ_MINIMIZER_SMALL);
+}
 
 /* Reverse the order of the 32 two-bit symbols of x. */
 CQ_HD uint64_t cq_rev2(uint64_t x)
@@ -119,7 +135,6 @@ CQ_HD uint32_t cq_mmer_phi_wide(uint64_t f, uint32_t m)
 CQ_HD uint32_t cq_min_phi(uint64_t hmer, uint32_t h, uint32_t m)
 {
     uint32_t best = 0xFFFFFFFFu;
-#if CQ_MAX_MINIMIZER > 16
     if (m > 16) {
         const uint64_t wmask = (1ull << (2u * m)) - 1ull;
         for (uint32_t j = 0; j + m <= h; j++) {
@@ -128,7 +143,6 @@ CQ_HD uint32_t cq_min_phi(uint64_t hmer, uint32_t h, uint32_t m)
         }
         return best;
     }
-#endif
     const uint32_t mask = m >= 16 ? 0xFFFFFFFFu : (1u << (2u * m)) - 1u;
     for (uint32_t j = 0; j + m <= h; j++) {
         const uint32_t p = cq_mmer_phi((uint32_t)(hmer >> (2u * (h - m - j))) & mask, m);
@@ -159,9 +173,9 @@ CQ_HD uint32_t cq_bucket_of_minimizer(uint32_t min_phi, uint32_t n_buckets)
 }
 
 /* Home bucket of an h-mer key (host side; the kernel has fw and rc at hand already). */
-CQ_HD uint32_t cq_home_bucket(uint64_t key, uint32_t h, uint32_t n_buckets)
+CQ_HD uint32_t cq_home_bucket(uint64_t key, uint32_t h, uint32_t m, uint32_t n_buckets)
 {
-    return cq_bucket_of_minimizer(cq_min_phi(key, h, cq_minimizer_len(h)), n_buckets);
+    return cq_bucket_of_minimizer(cq_min_phi(key, h, m), n_buckets);
 }
 
 /* Layout of the device counter block (uint64 words) for G = n_genomes:

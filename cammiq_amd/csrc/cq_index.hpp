@@ -83,6 +83,7 @@ void advise_huge(const void *p, size_t bytes);
 // Device-ready image.  Everything is plain arrays so upload is a handful of memcpys.
 struct FlatImage {
     uint32_t hash_len = 0;
+    uint32_t minimizer_len = 0;   // m of this image (cq_device.h: 16, or 18 for large tables)
     uint64_t n_leaves[2] = {0, 0};
     uint64_t n_buckets = 0;       // hash range: a key's home bucket is in [0, n_buckets)
     uint64_t n_buckets_alloc = 0; // n_buckets + spill tail
@@ -103,16 +104,17 @@ int decode_table(const std::string &path, DecodedTable &out, std::string &err);
 void make_empty_table(uint32_t hash_len, DecodedTable &out);
 
 // Merge + lay out.  load_factor = average keys per 4-slot bucket (default 1.5).
-int build_image(const DecodedTable &u, const DecodedTable &d, double keys_per_bucket,
+// minimizer_len: 0 = cq_choose_minimizer_len(h, keys).
+int build_image(const DecodedTable &u, const DecodedTable &d, double keys_per_bucket, uint32_t minimizer_len,
                 FlatImage &img, std::string &err);
 
 // Optional on-disk cache of the finished image (cq_cache.cpp).
 struct SourceStamp { uint64_t size[4]; int64_t mtime_ns[4]; };   // index_u, .aux, index_d, .aux (0 = absent)
 bool stamp_sources(const std::string &path_u, const std::string &path_d, SourceStamp &s);
-bool save_image(const std::string &file, const SourceStamp &src, double kpb_override, const DecodedTable tab[2],
-                const FlatImage &img);
-bool load_image(const std::string &file, const SourceStamp &src, double kpb_override, uint64_t max_table_bytes,
-                DecodedTable tab[2], FlatImage &img);
+bool save_image(const std::string &file, const SourceStamp &src, double kpb_override, uint32_t m_override,
+                const DecodedTable tab[2], const FlatImage &img);
+bool load_image(const std::string &file, const SourceStamp &src, double kpb_override, uint32_t m_override,
+                uint64_t max_table_bytes, DecodedTable tab[2], FlatImage &img);
 
 // Host mirror of the device lookup (used by tests of the layout through the C ABI and by
 // build_image's self-check).  Returns the slot values for `key` (0,0 when absent).

@@ -16,7 +16,7 @@ struct DevIndex {
     const uint2 *leaf_rids;  // global leaf id -> (refID1, refID2)
     uint32_t n_buckets;      // hash range
     uint32_t hash_len;
-    uint32_t minimizer_len;  // cq_minimizer_len(hash_len)
+    uint32_t minimizer_len;  // m of this index's table (cq_device.h: 16, or 18 for large tables)
 };
 
 struct QueryArgs {
@@ -53,6 +53,7 @@ struct LaunchInfo {
     int lds_hist = 0;            // per-genome counters in an LDS histogram (1) or as global atomics (0)
     int fixed_shape = 0;         // 1: the instantiation with hash length and batch shape as compile-time constants
     int fixed_h = 0, fixed_read_len = 0;
+    int minimizer_len = 0;       // m of the index the launch ran against
     int blocks_per_cu = 0;       // resident workgroups per CU the persistent grid was sized for
 };
 

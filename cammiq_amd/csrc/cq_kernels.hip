@@ -435,20 +435,22 @@ __device__ __forceinline__ void decide(const QueryArgs &a, const Tile &t, uint32
 #define CQ_WAVES_PER_EU 6   /* register budget: 512 / 6 -> 80 VGPRs */
 #endif
 //
-// H, RL: 0 = hash length and batch shape are launch arguments (any index, any read length).  H = 26, RL = 100 / 150
-// is the SAME code with CAMMiQ's default hash length (main.cpp:335-346) and the benchmark read lengths folded in as
+// H, RL, M: 0 = hash length, batch shape and minimizer length are launch arguments (any index, any read length).
+// H = 26, RL = 100 / 150, M = 16 / 18 is the SAME code with CAMMiQ's default hash length (main.cpp:335-346), the
+// benchmark read lengths and the two minimizer lengths the layout chooses between (cq_device.h) folded in as
 // constants: the row stride, the windows / m-mer positions per read, the four small-division magics, every 2h shift
 // and the minimizer network's shape stop being SGPR-resident launch arguments.  Chosen by launch_classify when index
 // and batch match; results are those of the generic instantiation (tests/test_gpu_parity.py runs both).
 constexpr uint32_t magic_of_c(uint32_t d) { return d == 0 ? 0u : (uint32_t)(((1u << 19) + d - 1) / d); }
-template <int R, int CAP, bool SLOW, int H, int RL>
+template <int R, int CAP, bool SLOW, int H, int RL, int M>
 __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(CQ_WAVES_PER_EU, CQ_WAVES_PER_EU)))
 classify_kernel(DevIndex ix, QueryArgs a)
 {
     static_assert(SLOW || R * 4 <= 64, "a sub-tile's rows (R x <= 16 words) must fit one 16-byte load per lane");
-    static_assert((H == 0) == (RL == 0) && (H == 0 || (H >= 5 && H <= 31 && RL >= H && RL <= 255)), "H and RL are fixed together");
+    static_assert((H == 0) == (RL == 0) && (H == 0) == (M == 0) && (H == 0 || (H >= 5 && H <= 31 && RL >= H && RL <= 255 && M <= H && M <= CQ_MAX_MINIMIZER)),
+                  "H, RL and M are fixed together");
     constexpr bool FX = H != 0;
-    constexpr uint32_t cM = H < CQ_MAX_MINIMIZER ? H : CQ_MAX_MINIMIZER, cW = FX ? RL - H + 1 : 0, cP = cW + (H - cM);
+    constexpr uint32_t cM = M, cW = FX ? RL - H + 1 : 0, cP = cW + (H - cM);
     constexpr uint32_t cN = H - cM + 1;   // m-mers per window
     extern __shared__ __align__(16) uint32_t smem[];
     const uint32_t sw = FX ? (uint32_t)(RL + 15) / 16 : a.stride_words, swp = sw | 1u;
@@ -573,8 +575,7 @@ classify_kernel(DevIndex ix, QueryArgs a)
                 // all kPrePos positions of the group are hashed and stored, valid or not (a row of phi holds whole
                 // groups): positions past len - m get the hash of whatever follows the read and are never read by a
                 // valid window -- no per-position branch
-#if CQ_MAX_MINIMIZER > 16
-                if (m > 16) {   // experiment builds: 64-bit m-mers (cq_device.h)
+                if (m > 16) {   // large tables: 64-bit m-mers folded to 32 bits (cq_device.h)
                     const uint64_t wmask = (1ull << (2u * m)) - 1ull;
 #pragma unroll
                     for (uint32_t k = 0; k < kPrePos; k++) {
@@ -584,7 +585,6 @@ classify_kernel(DevIndex ix, QueryArgs a)
                     }
                     continue;
                 }
-#endif
 #pragma unroll
                 for (uint32_t k = 0; k < kPrePos; k++) {
                     const uint32_t f = (uint32_t)((w64 << (2u * k)) >> (64u - 2u * m));
@@ -902,16 +902,18 @@ namespace {
 // cost HIP runtime calls (hipFuncSetAttribute + hipOccupancyMaxActiveBlocksPerMultiprocessor: tens of
 // microseconds, 24 x per host-fed query when asked per chunk), so their answers are kept per (device, variant,
 // LDS bytes): the first launch of a shape pays, later launches look up.
-enum Variant { kV8 = 0, kV4 = 1, kV8h26r100 = 2, kV8h26r150 = 3, kVSlow = 4, kNVariants = 5 };
+enum Variant { kV8 = 0, kV4 = 1, kV8h26r100 = 2, kV8h26r150 = 3, kV8h26r100m18 = 4, kV8h26r150m18 = 5, kVSlow = 6, kNVariants = 7 };
 
 const void *variant_fn(int v)
 {
     switch (v) {
-    case kV8: return (const void *)classify_kernel<8, kFastCAP, false, 0, 0>;
-    case kV4: return (const void *)classify_kernel<4, kFastCAP, false, 0, 0>;
-    case kV8h26r100: return (const void *)classify_kernel<8, kFastCAP, false, 26, 100>;
-    case kV8h26r150: return (const void *)classify_kernel<8, kFastCAP, false, 26, 150>;
-    default: return (const void *)classify_kernel<kSlowR, kSlowCAP, true, 0, 0>;
+    case kV8: return (const void *)classify_kernel<8, kFastCAP, false, 0, 0, 0>;
+    case kV4: return (const void *)classify_kernel<4, kFastCAP, false, 0, 0, 0>;
+    case kV8h26r100: return (const void *)classify_kernel<8, kFastCAP, false, 26, 100, 16>;
+    case kV8h26r150: return (const void *)classify_kernel<8, kFastCAP, false, 26, 150, 16>;
+    case kV8h26r100m18: return (const void *)classify_kernel<8, kFastCAP, false, 26, 100, 18>;
+    case kV8h26r150m18: return (const void *)classify_kernel<8, kFastCAP, false, 26, 150, 18>;
+    default: return (const void *)classify_kernel<kSlowR, kSlowCAP, true, 0, 0, 0>;
     }
 }
 
@@ -950,10 +952,10 @@ hipError_t fast_resident(int dev, int v, size_t sm, int &n)
     return hipSuccess;
 }
 
-template <int R, int H, int RL>
+template <int R, int H, int RL, int M>
 void launch_one(const DevIndex &ix, const QueryArgs &a, unsigned grid, size_t sm, hipStream_t stream)
 {
-    hipLaunchKernelGGL((classify_kernel<R, kFastCAP, false, H, RL>), dim3(grid), dim3(kBlock), sm, stream, ix, a);
+    hipLaunchKernelGGL((classify_kernel<R, kFastCAP, false, H, RL, M>), dim3(grid), dim3(kBlock), sm, stream, ix, a);
 }
 
 // The fast kernel: persistent waves, each walking its own sub-tiles of R reads.
@@ -986,10 +988,12 @@ hipError_t launch_fast(int variant, const DevIndex &ix, QueryArgs &a, int n_cus,
         if (grid > need) grid = need;
         if (grid == 0) grid = 1;
         switch (variant) {
-        case kV4: launch_one<4, 0, 0>(ix, a, (unsigned)grid, sm, stream); break;
-        case kV8h26r100: launch_one<8, 26, 100>(ix, a, (unsigned)grid, sm, stream); break;
-        case kV8h26r150: launch_one<8, 26, 150>(ix, a, (unsigned)grid, sm, stream); break;
-        default: launch_one<8, 0, 0>(ix, a, (unsigned)grid, sm, stream); break;
+        case kV4: launch_one<4, 0, 0, 0>(ix, a, (unsigned)grid, sm, stream); break;
+        case kV8h26r100: launch_one<8, 26, 100, 16>(ix, a, (unsigned)grid, sm, stream); break;
+        case kV8h26r150: launch_one<8, 26, 150, 16>(ix, a, (unsigned)grid, sm, stream); break;
+        case kV8h26r100m18: launch_one<8, 26, 100, 18>(ix, a, (unsigned)grid, sm, stream); break;
+        case kV8h26r150m18: launch_one<8, 26, 150, 18>(ix, a, (unsigned)grid, sm, stream); break;
+        default: launch_one<8, 0, 0, 0>(ix, a, (unsigned)grid, sm, stream); break;
         }
         e = hipGetLastError();
         if (e != hipSuccess) break;
@@ -1032,18 +1036,21 @@ hipError_t launch_classify(const DevIndex &ix, QueryArgs a, int n_cus, hipStream
     int per_cu = a.use_lds_hist ? with : plain;
     int variant = R == 4 ? kV4 : kV8;
     const char *nofix = getenv("CAMMIQ_NO_FIXED_SHAPE");   // test / A-B knob: always the generic instantiation
-    if (R == 8 && ix.hash_len == 26 && !(nofix && atoi(nofix))) {
+    if (R == 8 && ix.hash_len == 26 && (ix.minimizer_len == 16 || ix.minimizer_len == 18) && !(nofix && atoi(nofix))) {
         int fx = -1;
-        if (a.wmax == 100 - 26 + 1 && a.stride_words == 7) fx = kV8h26r100;
-        if (a.wmax == 150 - 26 + 1 && a.stride_words == 10) fx = kV8h26r150;
+        const bool m18 = ix.minimizer_len == 18;
+        if (a.wmax == 100 - 26 + 1 && a.stride_words == 7) fx = m18 ? kV8h26r100m18 : kV8h26r100;
+        if (a.wmax == 150 - 26 + 1 && a.stride_words == 10) fx = m18 ? kV8h26r150m18 : kV8h26r150;
         if (fx >= 0) {
             int n = 0;   // same LDS layout as the generic kernel of this shape; its own register count
             if ((e = fast_resident(dev, fx, smem_bytes(8, kFastCAP, a, a.use_lds_hist != 0), n)) != hipSuccess) return e;
             if (n >= per_cu) { variant = fx; per_cu = n; }
         }
     }
-    if (info) { info->reads_per_subtile = R; info->hit_slots = kFastCAP; info->lds_hist = (int)a.use_lds_hist; info->fixed_shape = variant >= kV8h26r100 ? 1 : 0;
-                info->fixed_h = variant >= kV8h26r100 ? 26 : 0; info->fixed_read_len = variant == kV8h26r100 ? 100 : variant == kV8h26r150 ? 150 : 0;
+    if (info) { info->reads_per_subtile = R; info->hit_slots = kFastCAP; info->lds_hist = (int)a.use_lds_hist; info->fixed_shape = (variant >= kV8h26r100 && variant != kVSlow) ? 1 : 0;
+                info->fixed_h = variant >= kV8h26r100 ? 26 : 0;
+                info->fixed_read_len = (variant == kV8h26r100 || variant == kV8h26r100m18) ? 100 : (variant == kV8h26r150 || variant == kV8h26r150m18) ? 150 : 0;
+                info->minimizer_len = (int)ix.minimizer_len;
                 info->blocks_per_cu = per_cu; }
     if (ev_start) { e = hipEventRecord(ev_start, stream); if (e != hipSuccess) return e; }
     e = launch_fast(variant, ix, a, n_cus, per_cu, stream);
@@ -1056,7 +1063,7 @@ hipError_t launch_classify(const DevIndex &ix, QueryArgs a, int n_cus, hipStream
         uint64_t grid = (uint64_t)n_cus;
         const uint64_t need = a.n_reads / 32000 + 1;
         if (a.use_lds_hist && grid < need) grid = need;
-        hipLaunchKernelGGL((classify_kernel<kSlowR, kSlowCAP, true, 0, 0>), dim3((unsigned)grid), dim3(kBlock), sm, stream, ix, a);
+        hipLaunchKernelGGL((classify_kernel<kSlowR, kSlowCAP, true, 0, 0, 0>), dim3((unsigned)grid), dim3(kBlock), sm, stream, ix, a);
         e = hipGetLastError();
         if (e != hipSuccess) return e;
         if (ev_stop) e = hipEventRecord(ev_stop, stream);

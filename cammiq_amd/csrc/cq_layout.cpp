@@ -65,8 +65,16 @@ void HugeWords::alloc(size_t words)
 
 void HugeWords::reset()
 {
-    if (base_) (void)munmap(base_, map_len_);
-    else delete[] p_;
+    // A mapping of tens of GB goes back in pieces: one munmap of configs[4]'s 80 GB image holds the process's
+    // mmap lock for ~5 s, during which every other thread's mmap / hipMalloc / stream creation waits (measured:
+    // "streams 4831 ms" in the load timing, while the release thread was running); 256 MiB pieces hold it for
+    // milliseconds each.
+    if (base_) {
+        const size_t piece = 256u << 20;
+        size_t left = map_len_;
+        while (left > piece) { left -= piece; (void)munmap((char *)base_ + left, piece); }
+        (void)munmap(base_, left);
+    } else delete[] p_;
     base_ = nullptr;
     map_len_ = 0;
     p_ = nullptr;
@@ -216,13 +224,16 @@ struct StageTimer {   // CAMMIQ_LOAD_TIMING=1: stage timings on stderr (diagnost
 };
 }  // namespace
 
-int build_image(const DecodedTable &u, const DecodedTable &d, double keys_per_bucket,
+int build_image(const DecodedTable &u, const DecodedTable &d, double keys_per_bucket, uint32_t minimizer_len,
                 FlatImage &img, std::string &err)
 {
     StageTimer st;
     img = FlatImage();
     if (u.hash_len != d.hash_len) { err = "hash lengths of the two index files differ"; return CQ_ERR_HASHLEN; }
     img.hash_len = u.hash_len;
+    if (minimizer_len == 0) minimizer_len = cq_choose_minimizer_len(u.hash_len, u.bucket_key.size() + d.bucket_key.size());
+    if (minimizer_len > CQ_MAX_MINIMIZER || minimizer_len > u.hash_len) { err = "minimizer length outside [1, min(h, 21)]"; return CQ_ERR_ARG; }
+    img.minimizer_len = minimizer_len;
     const uint64_t nu = u.leaves.size(), nd = d.leaves.size();
     if (nu + nd >= 0x7FFFFFFFull) { err = "more than 2^31-1 leaves in total"; return CQ_ERR_LIMIT; }
     img.n_leaves[0] = nu;
@@ -336,10 +347,10 @@ int build_image(const DecodedTable &u, const DecodedTable &d, double keys_per_bu
     // ... then the home buckets (a minimizer scan per key: the expensive part) on all cores
     {
         const unsigned nt = worker_count(n_ent);
-        const uint32_t hl = img.hash_len;
+        const uint32_t hl = img.hash_len, ml = img.minimizer_len;
         parallel_for(nt, [&](unsigned t) {
             const size_t lo = n_ent * t / nt, hi = n_ent * (t + 1) / nt;
-            for (size_t i = lo; i < hi; i++) ent[i].home = cq_home_bucket(ent[i].key, hl, n_buckets);
+            for (size_t i = lo; i < hi; i++) ent[i].home = cq_home_bucket(ent[i].key, hl, ml, n_buckets);
         });
     }
     if (img.nodes.size() >= (1ull << 30)) { err = "more than 2^30 trie nodes after path compression"; return CQ_ERR_LIMIT; }
@@ -520,7 +531,7 @@ int build_image(const DecodedTable &u, const DecodedTable &d, double keys_per_bu
 void image_lookup(const FlatImage &img, uint64_t key, uint32_t &val_u, uint32_t &val_d, uint32_t *chain_len)
 {
     val_u = val_d = 0;
-    uint64_t b = cq_home_bucket(key, img.hash_len, (uint32_t)img.n_buckets);
+    uint64_t b = cq_home_bucket(key, img.hash_len, img.minimizer_len, (uint32_t)img.n_buckets);
     const uint32_t klo = (uint32_t)key, khi = (uint32_t)(key >> 32);
     uint32_t chain = 0;
     for (;;) {

@@ -36,7 +36,23 @@
 extern "C" {
 #endif
 
-#define CQ_ABI_VERSION 3
+#define CQ_ABI_VERSION 4   /* 4: cq_last_launch_info; every host-fed SC-mode query starts from an empty pair map */
+
+/*
+ * Design limits of one handle (= one GPU's replica of the index).  The reference's pointer trie has none beyond its
+ * host's memory (hashtrie.hpp:8-13,37-50; util.hpp:12-14 bounds genomes, not markers); here cq_index_load returns
+ * CQ_ERR_LIMIT with a message, never a wrapped index:
+ *     markers (leaves of ht_u + ht_d)   <= 2^31 - 2     trie codes keep two flag bits of their 32 (cq_device.h)
+ *     trie nodes after path compression <  2^30
+ *     table buckets                     <  2^32          (one bucket per key by default: implied by the leaf limit)
+ *     key length                        <= 255          (as the reference: pleafNode::depth is a uint8_t)
+ * 2.1e9 markers are ~137 GB of table + ~26 GB of refIDs and rcount on the device (of 288 GB) and ~1.7 x RefSeq-scale
+ * (1-2e8 markers per 1000 bacterial genomes -> 1.5-3e9 for configs[4]'s ~15 000): an index beyond the
+ * limit is served by splitting its GENOMES over two handles / GPUs -- the markers of a genome subset are a valid
+ * index, and cnt_u/cnt_d/rcount of disjoint marker sets do not add up to the whole (a read's decision looks at all
+ * its hits), so that split needs the two hit lists merged before the decision: not built, stated here as the limit.
+ * Measured at 1.26e9 markers (15 000 genomes x 3.45 Mbp at the survey's density): DESIGN.md section 6.3.
+ */
 
 typedef enum cq_status {
     CQ_OK = 0,
@@ -48,7 +64,7 @@ typedef enum cq_status {
     CQ_ERR_NO_DEVICE = -6, /* no HIP device / handle was loaded host-only */
     CQ_ERR_HIP = -7,       /* a HIP runtime call failed */
     CQ_ERR_NOMEM = -8,
-    CQ_ERR_LIMIT = -9,     /* more than 2^31-1 leaves / nodes, 2^32 table buckets, key longer than 255, pair arrays too small */
+    CQ_ERR_LIMIT = -9,     /* a design limit above is exceeded, or the caller's pair arrays are too small */
     CQ_ERR_COMM = -10      /* an RCCL call failed (multi-GPU entry points) */
 } cq_status;
 
@@ -88,6 +104,8 @@ typedef struct cq_index_info {
     uint32_t max_chain;        /* longest bucket chain a lookup can walk */
     uint32_t reserved_;        /* 1 when the image came from the CAMMIQ_IMAGE_CACHE=1 file "<path_u>.cqimg" */
     uint64_t device_bytes;     /* HBM held by this handle */
+    uint32_t minimizer_len;    /* m-mer length the table is addressed by: 16, or 18 from 3e8 keys on (cq_device.h) */
+    uint32_t reserved2_;
 } cq_index_info;
 
 /*
@@ -258,7 +276,7 @@ typedef struct cq_launch_info {
     int32_t fixed_hash_len;   /* 0 unless fixed_shape */
     int32_t fixed_read_len;   /* 0 unless fixed_shape */
     int32_t blocks_per_cu;    /* resident workgroups per CU the persistent grid was sized for */
-    int32_t reserved;
+    int32_t minimizer_len;    /* m of the index (16 / 18): part of the instantiation's name when fixed_shape */
 } cq_launch_info;
 int cq_last_launch_info(cq_index *idx, cq_launch_info *out);
 

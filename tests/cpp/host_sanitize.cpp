@@ -27,17 +27,20 @@ int main(int argc, char **argv)
         if (rc != CQ_OK) { printf("decode_d %d %s\n", rc, err.c_str()); return 0; }
     } else cq::make_empty_table(u.hash_len, d);
     cq::FlatImage img;
-    rc = cq::build_image(u, d, 0.0, img, err);
-    if (rc != CQ_OK) { printf("layout %d %s\n", rc, err.c_str()); return 0; }
-    // every bucket key must be found again, with a sane chain length
     uint64_t found = 0;
-    for (const cq::DecodedTable *t : {&u, &d})
-        for (uint64_t k : t->bucket_key) {
-            uint32_t vu, vd, chain;
-            cq::image_lookup(img, k, vu, vd, &chain);
-            if ((vu | vd) == 0 || chain > img.max_chain) { printf("LOOKUP FAILED\n"); return 1; }
-            found++;
-        }
+    // the table addressed by 18-mer minimizers (large tables; 64-bit m-mers), then by the automatic choice
+    for (uint32_t mlen : {18u, 0u}) {
+        rc = cq::build_image(u, d, 0.0, mlen ? std::min(mlen, u.hash_len) : 0u, img, err);
+        if (rc != CQ_OK) { printf("layout %d %s\n", rc, err.c_str()); return 0; }
+        // every bucket key must be found again, with a sane chain length
+        for (const cq::DecodedTable *t : {&u, &d})
+            for (uint64_t k : t->bucket_key) {
+                uint32_t vu, vd, chain;
+                cq::image_lookup(img, k, vu, vd, &chain);
+                if ((vu | vd) == 0 || chain > img.max_chain) { printf("LOOKUP FAILED\n"); return 1; }
+                found++;
+            }
+    }
     // pack the reads (one per line; anything goes)
     std::ifstream in(argv[3], std::ios::binary);
     std::vector<uint8_t> bases;

@@ -395,3 +395,34 @@ def test_fixed_shape_instantiation_equals_the_generic_kernel(tmp_path, monkeypat
     ix = cq.Index(pu, pd, device=0)
     ix.query(*synth.concat_reads(reads[:2000] + [b"ACGT" * 50]), len(gen))
     assert ix.last_launch_info()["fixed_shape"] == 0
+
+
+@pytest.mark.parametrize("mlen", ["14", "17", "18", "21"])
+def test_minimizer_length_does_not_change_the_result(tmp_path, monkeypatch, mlen):
+    """The layout addresses large tables by 18-mer minimizers (36-bit m-mers folded to a 32-bit hash) instead of
+    16-mers (cq_device.h); CAMMIQ_MINIMIZER_LEN forces a length on any table.  Generic and fixed-shape
+    instantiations (h = 26: 100-bp and 150-bp batches have their own m = 18 builds), deep keys, both modes, against
+    the oracle; then another hash length through the generic kernel."""
+    monkeypatch.setenv("CAMMIQ_MINIMIZER_LEN", mlen)
+    gen = synth.clade_genomes(91, 3, 4, 4000, 0.03)
+    u, d = synth.select_markers(gen, 26, 48, keep_every=2, seed=8)
+    pu, pd = build_index(tmp_path, u, d, 26)
+    oi = oracle_lib.OracleIndex(pu, pd)
+    for rl in (100, 150, (30, 220)):
+        reads = synth.simulate_reads(gen, 12007, rl, 0.01, 6, frac_random=0.1)
+        b, o = synth.concat_reads(reads)
+        for mode in (cq.MODE_P, cq.MODE_SC):
+            ref = oi.query(b, o, len(gen), mode=mode, nthreads=8)
+            ix = cq.Index(pu, pd, device=0)
+            assert ix.info_dict()["minimizer_len"] == int(mlen)
+            got = ix.query(b, o, len(gen), mode=mode)
+            li = ix.last_launch_info()
+            assert li["minimizer_len"] == int(mlen)
+            assert li["fixed_shape"] == (1 if (mlen == "18" and isinstance(rl, int)) else 0), (li, rl)
+            assert_same(got, ref, f"m={mlen} rl={rl} mode={mode}", rcount=(mode == cq.MODE_P))
+            assert got["pairs"] == ref["pairs"]
+    gen = synth.clade_genomes(5, 2, 3, 2500, 0.04)
+    u, d = synth.select_markers(gen, 20, 36, keep_every=2, seed=3)
+    pu, pd = build_index(tmp_path, u, d, 19, "h19")
+    got, ref = _both(pu, pd, synth.simulate_reads(gen, 6000, (19, 255), 0.01, 2, frac_random=0.1), len(gen))
+    assert_same(got, ref, f"h=19 m={mlen}")

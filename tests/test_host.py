@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name), f"{name} declared in cammiq_hip.h but not exported"
     assert declared == set(binding.SIGNATURES), (declared ^ set(binding.SIGNATURES))
-    assert binding.lib().cq_abi_version() == 3
+    assert binding.lib().cq_abi_version() == 4
 
 
 def test_oracle_is_not_linked_into_the_product():
@@ -40,10 +40,16 @@ def test_oracle_is_not_linked_into_the_product():
                 assert "oracle_lib" not in txt and "liboracle" not in txt and "cqo_" not in txt, f
 
 
+@pytest.mark.parametrize("mlen", [None, "11", "17", "18", "21"])
 @pytest.mark.parametrize("name", ["f_deep", "f_flat", "survey_F1", "survey_F2"])
-def test_decoder_matches_oracle_and_pyref(name):
+def test_decoder_matches_oracle_and_pyref(name, mlen, monkeypatch):
+    """mlen: the minimizer length the table is addressed by is a property of the index (cq_device.h: 16, or 18 for
+    large tables; CAMMIQ_MINIMIZER_LEN overrides).  Whatever it is, the table must find exactly the file's buckets."""
     g = golden(name)
+    if mlen:
+        monkeypatch.setenv("CAMMIQ_MINIMIZER_LEN", mlen)
     ix = cq.Index(g["pu"], g["pd"], device=-1)
+    assert ix.info_dict()["minimizer_len"] == min(ix.hash_len, int(mlen) if mlen else 16)
     oi = oracle_lib.OracleIndex(g["pu"], g["pd"])
     assert ix.hash_len == oi.hash_len and ix.n_leaves == oi.n_leaves
     assert list(ix.info.n_file_buckets) == oi.n_buckets

@@ -24,17 +24,22 @@ def driver(tmp_path_factory):
     return out
 
 
-def _run(driver, pu, pd, reads):
-    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+DECODERS = {"serial": {"CAMMIQ_DECODE_THREADS": "1"},
+            "chunked": {"CAMMIQ_DECODE_THREADS": "4", "CAMMIQ_DECODE_STEP": "3"}}   # scan + parallel chunks of 3 buckets
+
+
+def _run(driver, pu, pd, reads, decoder="serial"):
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1", **DECODERS[decoder])
     return subprocess.run([driver, pu, pd or "-", reads], capture_output=True, text=True, env=env)
 
 
+@pytest.mark.parametrize("decoder", sorted(DECODERS))
 @pytest.mark.parametrize("name", ["f_deep", "f_flat", "survey_F2"])
-def test_host_code_is_clean_under_asan_ubsan(driver, tmp_path, name):
+def test_host_code_is_clean_under_asan_ubsan(driver, tmp_path, name, decoder):
     g = golden(name)
     reads = tmp_path / "reads.txt"
     reads.write_bytes(b"\n".join(g["reads"][:2000]) + b"\nACGTNNNN\n\n" + bytes(range(1, 10)) + b"\n")
-    r = _run(driver, g["pu"], g["pd"], str(reads))
+    r = _run(driver, g["pu"], g["pd"], str(reads), decoder)
     assert r.returncode == 0 and "\nok " in "\n" + r.stdout and "meta loaded" in r.stdout, r.stdout + r.stderr
     assert "ERROR" not in r.stderr and "runtime error" not in r.stderr, r.stderr
 
@@ -57,7 +62,11 @@ def test_corrupted_indices_under_asan_ubsan(driver, tmp_path):
             for _ in range(rng.randrange(1, 6)):
                 data[rng.randrange(len(data))] ^= 1 << rng.randrange(8)
         (tmp_path / f).write_bytes(bytes(data))
-        r = _run(driver, str(tmp_path / files[0]), str(tmp_path / files[2]), str(reads))
-        assert r.returncode == 0, (trial, f, r.stdout, r.stderr[-2000:])
-        assert "AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-2000:]
+        outs = []
+        for decoder in sorted(DECODERS):
+            r = _run(driver, str(tmp_path / files[0]), str(tmp_path / files[2]), str(reads), decoder)
+            assert r.returncode == 0, (trial, f, decoder, r.stdout, r.stderr[-2000:])
+            assert "AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-2000:]
+            outs.append(r.stdout)
+        assert outs[0] == outs[1], "the chunked decoder and the serial one disagree on a corrupted file"
         (tmp_path / f).write_bytes(good[f])

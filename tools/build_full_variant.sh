@@ -1,7 +1,7 @@
 #!/bin/bash
 # tools/build_full_variant.sh NAME [extra compiler flags...]
 # Builds variants/libcammiq_NAME.so with EVERY source of the library compiled with the extra flags -- for experiments
-# that change what host layout and kernel share (cq_device.h), e.g. -DCQ_MAX_MINIMIZER=18.  (tools/build_variant.sh
+# that change what host layout and kernel share (cq_device.h), e.g. -DCQ_RUN_SLOTS=4.  (tools/build_variant.sh
 # only recompiles the kernels.)  Same-box A/B through CAMMIQ_LIB / tools/kexp.py.
 set -euo pipefail
 root="$(cd "$(dirname "$0")/.." && pwd)"

@@ -105,7 +105,8 @@ def run(genomes=15000, genome_len=3_450_000, n_reads=20_000_000, rl=150, slice_r
                         "device_GB": round(info["device_bytes"] / 1e9, 2), "keys": info["n_keys"],
                         "overflowed_buckets": info["n_overflowed"],
                         "overflowed_pct": round(100.0 * info["n_overflowed"] / max(1, info["n_table_buckets"]), 3),
-                        "max_chain": info["max_chain"], "trie_nodes": info["n_trie_nodes"]}
+                        "max_chain": info["max_chain"], "trie_nodes": info["n_trie_nodes"],
+                        "minimizer_len": info.get("minimizer_len")}
         log(f"[configs4] table {rec['table']}")
         for p in (pu, pu + ".aux", pd, pd + ".aux"):
             os.unlink(p)                       # give the page cache back before the reads are generated
