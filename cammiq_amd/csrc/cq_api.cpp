@@ -745,19 +745,11 @@ int classify_range(cq_index *ix, int mode, const Feed &f, uint64_t lo, uint64_t 
     uint64_t c = 0;
     // inside the loop a failed HIP call ends the loop instead of returning: copies from the caller's memory may be in flight
 #define CQ_HIPB(call) if (hipError_t e_ = (call)) { rc = fail(CQ_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); break; } else (void)0
-    // Chunk schedule.  The first chunk's copy and the last chunk's kernel have nothing to hide behind (~1 ms each at
-    // 2 M reads), so long inputs ramp: 1/4, 1/2 chunk at either end, full chunks between (same reads, same
-    // order, same results; CAMMIQ_CHUNK_RAMP=0 turns it off for A/B timing).
+    // Chunk schedule: equal chunks.  (Ramping the ends -- 1/4 and 1/2 chunks first and last, so that the first copy
+    // and the last kernel expose less -- was measured on configs[2]: 31.26 / 31.22 ms against 31.55 / 31.12 ms without,
+    // A/B/A/B on one box: the copy queue is the critical path, the last kernel's 0.9 ms is all a ramp can shorten.)
     std::vector<uint64_t> sched;
-    {
-        static const bool ramp_on = !(getenv("CAMMIQ_CHUNK_RAMP") && atoi(getenv("CAMMIQ_CHUNK_RAMP")) == 0);
-        uint64_t left = hi - lo;
-        const bool ramp = ramp_on && kChunk >= 4096 && left >= 6 * kChunk;
-        if (ramp) { sched.push_back(kChunk / 4); sched.push_back(kChunk / 2); left -= kChunk / 4 + kChunk / 2; }
-        const uint64_t tail = ramp ? kChunk / 2 + kChunk / 4 : 0;
-        while (left > tail) { const uint64_t n = std::min(kChunk, left - tail); sched.push_back(n); left -= n; }
-        if (ramp) { sched.push_back(kChunk / 2); sched.push_back(kChunk / 4); }
-    }
+    for (uint64_t left = hi - lo; left > 0;) { const uint64_t n = std::min(kChunk, left); sched.push_back(n); left -= n; }
     uint64_t c0 = lo;
     for (size_t ci = 0; ci < sched.size() && rc == CQ_OK; c0 += sched[ci], ci++, c++) {
         cq_index::Slot &sl = ix->slot[c % 3];

@@ -22,7 +22,7 @@ from util import assert_same, build_index
 pytestmark = pytest.mark.gpu
 
 _KNOBS = ("CAMMIQ_MAX_SUB_PER_WAVE", "CAMMIQ_LDS_HIST_MAX", "CAMMIQ_KEYS_PER_BUCKET", "CAMMIQ_BLOCKS_PER_CU",
-          "CAMMIQ_PAIR_SLOTS", "CAMMIQ_FAST_R")
+          "CAMMIQ_PAIR_SLOTS", "CAMMIQ_FAST_R", "CAMMIQ_MINIMIZER_LEN", "CAMMIQ_NO_FIXED_SHAPE")
 
 
 def _draw(seed):
@@ -56,6 +56,11 @@ def _draw(seed):
         w["env"]["CAMMIQ_PAIR_SLOTS"] = r.choice(["16", "64"])               # SC mode has to grow the pair table
     if r.random() < 0.4:
         w["env"]["CAMMIQ_FAST_R"] = r.choice(["4", "8"])                     # reads per wave sub-tile, either way at any length
+    # (drawn last: worlds of earlier campaigns keep every other parameter)
+    if r.random() < 0.45:
+        w["env"]["CAMMIQ_MINIMIZER_LEN"] = r.choice(["9", "13", "15", "17", "18", "18", "19", "21"])   # the table's address length (16 / 18 by size otherwise)
+    if r.random() < 0.25:
+        w["env"]["CAMMIQ_NO_FIXED_SHAPE"] = "1"                              # h = 26 at 100 / 150 bp: the generic instantiation instead
     return w
 
 
@@ -158,6 +163,10 @@ def _draw_generator(seed):
         w["env"]["CAMMIQ_PAIR_SLOTS"] = "64"
     if r.random() < 0.4:
         w["env"]["CAMMIQ_FAST_R"] = r.choice(["4", "8"])
+    if r.random() < 0.5:
+        w["env"]["CAMMIQ_MINIMIZER_LEN"] = r.choice(["14", "17", "18", "18", "20"])   # large tables use 18 by themselves
+    if r.random() < 0.25:
+        w["env"]["CAMMIQ_NO_FIXED_SHAPE"] = "1"
     return w
 
 
