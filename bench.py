@@ -401,33 +401,27 @@ def main():
                 assert np.array_equal(rcd.cpu().numpy().view(np.uint32)[:nu], hq["rcount_u"])
 
         # ---- second N > 1 shape: ONE process, one host thread per GPU inside the library, the library's
-        #      own RCCL all-reduce -- the same host-fed query over min(2, visible GPUs) devices must give the counts
-        #      of the single-device query above.  A secondary leg: a failure is recorded in the line, never hidden.
+        #      own RCCL reduction -- the same kind of host-fed query over min(2, visible GPUs) devices must give the counts
+        #      of a single device.  It runs in a CHILD process with a time limit (tools/multi_leg.py), after everything this
+        #      line reports has been measured: RCCL's first contact with two ranks cannot take the headline down with it.
+        #      A failure is recorded in the line (and fails the run only when the counts DIFFER), never hidden.
         if rank == 0 and multi_leg:
-            devs = list(range(min(2, n_vis)))
+            import subprocess
+            ndev = min(2, n_vis)
+            nm = min(n, 20_000_000)
+            cmd = [sys.executable, os.path.join(ROOT, "tools", "multi_leg.py"), pu, pd or "-", str(G), str(args.genome_len),
+                   "1" if both else "0", str(nm), str(rl), str(ndev)]
             try:
-                t0 = time.perf_counter()
-                mm = cq.Multi(pu, pd, devs)
-                t_mload = time.perf_counter() - t0
-                mout = mm.shards[0].counts_out(G, pinned=True)
-                mm.query_packed_tight(h_packed[0][:1 << 16], h_lens[0][:1 << 16], rl, G, out=mout)
-                ts = []
-                for _ in range(2):
-                    t0 = time.perf_counter()
-                    mq = mm.query_packed_tight(h_packed[0], h_lens[0], rl, G, out=mout)
-                    ts.append(time.perf_counter() - t0)
-                same = all(np.array_equal(mq[kk], hq[kk]) for kk in ("cnt_u", "cnt_d", "rcount_u", "rcount_d")) \
-                    and mq["nundet"] == hq["nundet"] and mq["nconf"] == hq["nconf"]
-                result["multi_in_process"] = {
-                    "devices": devs, "Mreads_s": round(n / min(ts) / 1e6, 2), "ms": round(min(ts) * 1e3, 3),
-                    "equals_single_device": bool(same), "load_s": round(t_mload, 2),
-                    "what": "cq_multi_query_packed_tight: reads sharded over the devices by cq_shard_range, one host thread "
-                            "per device, ncclAllReduce of counter block + rcount inside libcammiq_hip.so, host takes device 0"}
-                mm.close()
-                if not same:
+                r = subprocess.run(cmd, capture_output=True, text=True, timeout=float(os.environ.get("CAMMIQ_MULTI_LEG_TIMEOUT", "300")))
+                lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+                if lines:
+                    result["multi_in_process"] = json.loads(lines[-1])
+                else:
+                    result["multi_in_process"] = {"devices": list(range(ndev)), "error": f"exit status {r.returncode}: {r.stderr[-600:]}"}
+                if r.returncode == 3:
                     raise SystemExit("multi-GPU (one process) counts differ from the single-device counts")
-            except cq.CammiqError as e:
-                result["multi_in_process"] = {"devices": devs, "error": str(e)}
+            except subprocess.TimeoutExpired:
+                result["multi_in_process"] = {"devices": list(range(ndev)), "error": "no result within the time limit (child killed)"}
 
         if rank == 0 and world == 1 and args.ascii_api and sample_bases is not None:
             so = np.arange(ns + 1, dtype=np.uint64) * np.uint64(rl)

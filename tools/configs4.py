@@ -50,10 +50,13 @@ def peak_rss_gb() -> float:
     return resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1e6
 
 
-def size_for_this_box(genomes: int, want_len: int, host_budget_bytes: float | None = None):
+def size_for_this_box(genomes: int, want_len: int, host_budget_bytes: float | None = None, shm_bytes: float | None = None):
     """Largest genome length <= want_len whose index this box can build (host memory is the limit, not HBM)."""
     avail = mem_available_bytes() if host_budget_bytes is None else host_budget_bytes
-    shm = shutil.disk_usage("/dev/shm").free if os.path.isdir("/dev/shm") else avail
+    if shm_bytes is not None:
+        shm = shm_bytes
+    else:
+        shm = shutil.disk_usage("/dev/shm").free if os.path.isdir("/dev/shm") else avail
     budget = min(0.72 * avail, 260e9)                 # a one-GPU lease is capped at ~270 GiB of host memory
     markers = budget / BYTES_PER_MARKER_HOST_PEAK
     markers = min(markers, 0.8 * shm / 16)            # ~14.8 bytes of index file per marker
