@@ -63,7 +63,8 @@
  *           where the table has 4 slots: 9.6 % of the buckets overflowed, chains up to 9, and the kernel took
  *           39.0 ms per 20 M x 150-bp reads; m = 17: 4.6 %, 21.3 ms; m = 18 (w = 9; 36-bit m-mers folded to 32 bits by
  *           cq_phi_wide -- not a bijection, which the scheme does not need: only the minimum VALUE is used, and host
- *           and device take it over the same m-mers): 3.7 %, 20.0 ms (profiles/r03_cfg4_*).  Shorter
+ *           and device take it over the same m-mers): 3.7 %, 20.0 ms with a uniform fold, 1.2 % and 17.5 ms with the
+ *           fold that gives the small values more room (cq_phi_wide; DESIGN 3.2, profiles/r03_cfg4_*).  Shorter
  *           runs (5 positions) are the price: on configs[2]'s 84 M keys m = 18 is slower than m = 16. */
 #define CQ_MAX_MINIMIZER 21               /* k + m <= 32 for the pre-pass's 11 positions per 64-bit piece */
 #define CQ_MINIMIZER_SMALL 16
@@ -116,12 +117,26 @@ CQ_HD uint32_t cq_mmer_phi(uint32_t f, uint32_t m)
 }
 
 /* The same for 16 < m <= 21: the canonical m-mer is up to 42 bits; its low word goes through phi's multiply, the
- * high bits (< 2^10) through a second, 24-bit one (full rate on CDNA), then one xorshift. */
+ * high bits (< 2^10) through a second, 24-bit one (full rate on CDNA), then one xorshift: x, a uniform 32-bit value.
+ *
+ * x alone is not what is returned.  The bucket address is a function of the MINIMUM of a key's w = h-m+1 values, and
+ * minima crowd the small values: N keys put N w (1-x)^(w-1) / 2^32 keys on value x -- 2.6 on every small one for
+ * configs[4]'s 1.26e9 keys, whatever the number of buckets (3.7 % of them overflowed).  So the small values get more
+ * room: two further bits e2 of the m-mer's identity extend x to 34 bits, and a monotone piecewise-linear map takes
+ * (x, e2) back to 32 bits with slope 4 below 1/8, 2 up to 1/4, 1/2 up to 1/2 and 1/4 above -- a coarse version of
+ * 1 - (1-x)^8, the map that would make the minimum of nine values uniform.  Being monotone it selects the same
+ * minimizer as x would (up to ties that e2 now breaks); the keys per address drop from 2.6 to 0.66 where they were
+ * densest (Monte Carlo of the placement: 3.2 % -> 0.65 % overflowed buckets; uniform addresses: 0.4 %). */
 CQ_HD uint32_t cq_phi_wide(uint64_t c)
 {
-    uint32_t x = (uint32_t)c * 0x9E3779B1u + (((uint32_t)(c >> 32) + 1u) & 0xFFFFFFu) * 0x85EBCBu;
+    const uint32_t lo = (uint32_t)c, hi = ((uint32_t)(c >> 32) + 1u) & 0xFFFFFFu;
+    uint32_t x = lo * 0x9E3779B1u + hi * 0x85EBCBu;
     x ^= x >> 15;
-    return x;
+    const uint32_t e2 = (lo * 0xC2B2AE35u + hi * 0x27D4EBu) >> 30;
+    if (x < (1u << 29)) return (x << 2) | e2;
+    if (x < (1u << 30)) return (1u << 31) + ((x - (1u << 29)) << 1) + (e2 >> 1);
+    if (x < (1u << 31)) return (1u << 31) + (1u << 30) + ((x - (1u << 30)) >> 1);
+    return (1u << 31) + (1u << 30) + (1u << 29) + ((x - (1u << 31)) >> 2);
 }
 
 CQ_HD uint32_t cq_mmer_phi_wide(uint64_t f, uint32_t m)

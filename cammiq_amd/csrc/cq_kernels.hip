@@ -38,6 +38,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <atomic>
 #include <mutex>
 #include <vector>
 
@@ -921,14 +922,14 @@ struct OccKey { int dev, variant; size_t smem; };
 struct OccEnt { OccKey k; int blocks; };
 std::mutex g_occ_mu;
 std::vector<OccEnt> g_occ;
-bool g_attr_done[64][kNVariants];   // hipFuncSetAttribute(160 KB of LDS) once per device and kernel
+std::atomic<bool> g_attr_done[64][kNVariants];   // hipFuncSetAttribute(160 KB of LDS) once per device and kernel (set from several host threads: cq_multi)
 
 hipError_t ensure_lds_optin(int dev, int v)
 {
-    if (dev >= 0 && dev < 64 && g_attr_done[dev][v]) return hipSuccess;
+    if (dev >= 0 && dev < 64 && g_attr_done[dev][v].load(std::memory_order_acquire)) return hipSuccess;
     // LDS above the 64 KiB default needs an explicit opt-in (large G, long reads, the slow path's hit lists)
     hipError_t e = hipFuncSetAttribute(variant_fn(v), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e == hipSuccess && dev >= 0 && dev < 64) g_attr_done[dev][v] = true;
+    if (e == hipSuccess && dev >= 0 && dev < 64) g_attr_done[dev][v].store(true, std::memory_order_release);
     return e;
 }
 

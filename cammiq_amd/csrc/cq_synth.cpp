@@ -420,7 +420,7 @@ static int write_index_impl(void *hh, const char *path_u, const char *path_d, ui
         lap(table ? "sort + dedupe (d)" : "sort + dedupe (u)");
         uint64_t n_leaves = 0;
         if (!emit_table(p, table, part, table ? path_d : path_u, n_leaves)) return -1;
-        if (sub) {
+        if (sub && (table ? sub->path_d : sub->path_u)) {
             // the sub-index: markers whose h-mer is in the set (a 2^27-bit filter in front of the binary search)
             std::vector<uint64_t> filt(1u << 21, 0);
             for (uint64_t i = 0; i < sub->n_hv; i++) { const uint64_t k = order_key(sub->hv[i]) >> 37; filt[k >> 6] |= 1ull << (k & 63); }
