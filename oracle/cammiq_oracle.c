@@ -676,6 +676,17 @@ static int64_t cqo_check_reads(const cqo_index *ix, const uint8_t *bases, const 
  */
 enum { CQO_VAR_SERIAL = 0, CQO_VAR_CRITICAL = 1, CQO_VAR_ATOMIC = 2, CQO_VAR_THREAD_LOCAL = 3 };
 
+#include <time.h>
+static double cqo_last_loop_s = 0.0;
+static double cqo_now(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+/* Seconds the most recent cqo_query* spent in its loop over the reads (the reference's "Time for query" bracket). */
+double cqo_last_loop_seconds(void) { return cqo_last_loop_s; }
+
 /* variant: CQO_VAR_SERIAL (query64_p), CQO_VAR_CRITICAL (query64mt_p as written: one global critical section per
  * read), CQO_VAR_ATOMIC (same loop, every shared counter an atomic), CQO_VAR_THREAD_LOCAL (per-thread cnt_u /
  * cnt_d / nundet / nconf / branch / read_cnts_b merged after the loop, rcount via atomics: SURVEY.md 8(d)'s
@@ -718,10 +729,17 @@ int64_t cqo_query_variant(cqo_index *ix, int mode, int nthreads, int variant,
     acc.cnt_u = cnt_u; acc.cnt_d = cnt_d;
     memset(cnt_u, 0, (size_t)(n_genomes + 1) * sizeof *cnt_u);
     memset(cnt_d, 0, (size_t)(n_genomes + 1) * sizeof *cnt_d);
-    for (int t = 0; t < 2; t++)
-        for (uint64_t i = 0; i < ix->ht[t].leaf_cnt; i++) ix->ht[t].leaves[i]->rcount = 0;
+    /* resetCounters (query.cpp:1820-1840).  10^8 heap nodes: on all cores, or this alone outlasts a bench sample */
+    for (int t = 0; t < 2; t++) {
+#pragma omp parallel for schedule(static)
+        for (int64_t i = 0; i < (int64_t)ix->ht[t].leaf_cnt; i++) ix->ht[t].leaves[i]->rcount = 0;
+    }
 
     if (nthreads < 1) nthreads = 1;
+    /* The reference's own "Time for query" (query.cpp:459,645-647) brackets the loop over the reads and nothing
+     * else -- resetCounters runs between files, outside it -- so the loop is timed on its own here: zeroing and
+     * reading back rcount of 10^8 heap nodes above / below takes longer than classifying a bench sample. */
+    const double t_loop0 = cqo_now();
     if (variant == CQO_VAR_SERIAL) {
         for (uint64_t r = 0; r < n_reads; r++)
             cqo_classify_read(ix, mode, bases + offsets[r], (size_t)(offsets[r + 1] - offsets[r]), &acc, 0);
@@ -764,8 +782,15 @@ int64_t cqo_query_variant(cqo_index *ix, int mode, int nthreads, int variant,
             cqo_classify_read(ix, mode, bases + offsets[r], (size_t)(offsets[r + 1] - offsets[r]), &acc, lock_mode);
     }
 
-    if (rcount_u) for (uint64_t i = 0; i < ix->ht[0].leaf_cnt; i++) rcount_u[i] = ix->ht[0].leaves[i]->rcount;
-    if (rcount_d) for (uint64_t i = 0; i < ix->ht[1].leaf_cnt; i++) rcount_d[i] = ix->ht[1].leaves[i]->rcount;
+    cqo_last_loop_s = cqo_now() - t_loop0;
+    if (rcount_u) {
+#pragma omp parallel for schedule(static)
+        for (int64_t i = 0; i < (int64_t)ix->ht[0].leaf_cnt; i++) rcount_u[i] = ix->ht[0].leaves[i]->rcount;
+    }
+    if (rcount_d) {
+#pragma omp parallel for schedule(static)
+        for (int64_t i = 0; i < (int64_t)ix->ht[1].leaf_cnt; i++) rcount_d[i] = ix->ht[1].leaves[i]->rcount;
+    }
     scal[0] = acc.nundet; scal[1] = acc.nconf;
     if (branch) memcpy(branch, acc.branch, sizeof acc.branch);
     if (n_pairs) {

@@ -48,6 +48,7 @@ def lib():
         L.cqo_query_variant.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64,
                                         C.c_uint32] + [C.c_void_p] * 9 + [C.c_uint64, C.c_void_p]
         L.cqo_omp_max_threads.restype = C.c_int
+        L.cqo_last_loop_seconds.restype = C.c_double
         _LIB = L
     return _LIB
 
@@ -105,7 +106,8 @@ class OracleIndex:
         k = int(npairs[0])
         pairs = {(int(pa[i]), int(pb[i])): int(pc[i]) for i in range(min(k, cap))}
         return dict(cnt_u=cu, cnt_d=cd, rcount_u=ru, rcount_d=rd, nundet=int(scal[0]),
-                    nconf=int(scal[1]), branch=dict(zip(BRANCHES, (int(x) for x in br))), pairs=pairs)
+                    nconf=int(scal[1]), branch=dict(zip(BRANCHES, (int(x) for x in br))), pairs=pairs,
+                    loop_s=float(lib().cqo_last_loop_seconds()))   # the loop over the reads alone ("Time for query" bracket)
 
     def close(self):
         if self.h:
