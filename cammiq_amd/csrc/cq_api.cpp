@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 #include <chrono>
+#include <functional>
 #include <map>
 #include <memory>
 
@@ -210,10 +211,24 @@ uint32_t pair_cap_from_env()
 // Host (pageable) -> device copy of a large array.  A plain hipMemcpy of pageable memory is staged by the runtime at
 // ~13 GB/s (configs[4]'s 80 GB table: 6 s); two page-locked 128 MiB pieces filled by eight memcpy threads while the
 // previous piece is on the link run at what the link gives.  Falls back to hipMemcpy for small arrays and on any error.
-hipError_t upload_array(void *dst, const void *src, size_t bytes)
+// fill(piece, offset, n): writes bytes [offset, offset + n) of the source into `piece` (called from eight threads on
+// disjoint ranges).  src != nullptr: the source is that array (fill may be empty) and small arrays / failures take a
+// plain hipMemcpy; src == nullptr: the source exists only through fill (e.g. two arrays interleaved on the fly).
+hipError_t upload_pieces(void *dst, const void *src, size_t bytes, const std::function<void(char *, size_t, size_t)> &fill)
 {
     const size_t piece = 128u << 20;
-    if (bytes < 4 * piece) return hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice);
+    if (bytes == 0) return hipSuccess;
+    auto staged = [&]() -> hipError_t {   // no contiguous source: through pageable memory, piece by piece
+        std::vector<char> tmp(std::min(piece, bytes));
+        for (size_t off = 0; off < bytes; off += tmp.size()) {
+            const size_t n = std::min(tmp.size(), bytes - off);
+            fill(tmp.data(), off, n);
+            hipError_t e = hipMemcpy((char *)dst + off, tmp.data(), n, hipMemcpyHostToDevice);
+            if (e != hipSuccess) return e;
+        }
+        return hipSuccess;
+    };
+    if (bytes < 4 * piece) return src ? hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice) : staged();   // small: not worth two page-locked buffers
     const auto t_begin = std::chrono::steady_clock::now();
     void *pin[2] = {nullptr, nullptr};
     hipEvent_t ev[2] = {nullptr, nullptr};
@@ -229,10 +244,11 @@ hipError_t upload_array(void *dst, const void *src, size_t bytes)
         if (!ok) break;
         const unsigned nt = 8;
         std::vector<std::thread> th;
-        const char *s0 = (const char *)src + done;
         char *d0 = (char *)pin[b];
-        for (unsigned t = 1; t < nt; t++) th.emplace_back([=] { memcpy(d0 + n * t / nt, s0 + n * t / nt, n * (t + 1) / nt - n * t / nt); });
-        memcpy(d0, s0, n / nt);
+        // sub-ranges on 64-byte boundaries (producers that interleave records must not split one)
+        auto cut = [&](unsigned t) { return t >= nt ? n : (n * t / nt) & ~(size_t)63; };
+        for (unsigned t = 1; t < nt; t++) th.emplace_back([&, t] { fill(d0 + cut(t), done + cut(t), cut(t + 1) - cut(t)); });
+        fill(d0, done, cut(1));
         for (auto &x : th) x.join();
         ok = hipMemcpyAsync((char *)dst + done, pin[b], n, hipMemcpyHostToDevice, st) == hipSuccess && hipEventRecord(ev[b], st) == hipSuccess;
         if (ok) done += n;
@@ -245,7 +261,13 @@ hipError_t upload_array(void *dst, const void *src, size_t bytes)
                 std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count(), ok && done == bytes ? "pinned pieces" : "fell back to hipMemcpy");
     if (ok && done == bytes) return hipSuccess;
     (void)hipGetLastError();
-    return hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice);   // whatever went wrong above: the plain copy decides
+    return src ? hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice) : staged();   // whatever went wrong above: the plain copies decide
+}
+
+hipError_t upload_array(void *dst, const void *src, size_t bytes)
+{
+    const char *s0 = (const char *)src;
+    return upload_pieces(dst, src, bytes, [s0](char *p, size_t off, size_t n) { memcpy(p, s0 + off, n); });
 }
 
 // Copy the flat image into the HBM of ix->device.
@@ -263,22 +285,27 @@ int upload(cq_index *ix)
     const size_t sb = img.table_words * sizeof(uint32_t);
     const size_t nb = img.nodes.size() * sizeof(cq::Node);
     const size_t nl = img.leaf_r1.size();
+    const bool timing = getenv("CAMMIQ_LOAD_TIMING") != nullptr;
+    auto t_up = std::chrono::steady_clock::now();
+    auto up_lap = [&](const char *what) {
+        const auto n = std::chrono::steady_clock::now();
+        if (timing) fprintf(stderr, "[cq_index_load]   %-22s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(n - t_up).count());
+        t_up = n;
+    };
     CQ_HIP(hipMalloc(&ix->d_slots, sb));
     CQ_HIP(hipMalloc(&ix->d_nodes, nb));
     CQ_HIP(hipMalloc(&ix->d_leaf_rids, std::max<size_t>(nl, 1) * sizeof(uint2)));
+    up_lap("hipMalloc (image)");
     CQ_HIP(upload_array(ix->d_slots, img.table.get(), sb));
-    CQ_HIP(hipMemcpy(ix->d_nodes, img.nodes.data(), nb, hipMemcpyHostToDevice));
-    {
-        std::unique_ptr<uint2[]> rr(new uint2[nl ? nl : 1]);
-        const unsigned nt = nl < (1u << 20) ? 1u : std::max(1u, std::min(std::thread::hardware_concurrency(), 16u));
-        std::vector<std::thread> th;
-        for (unsigned t = 0; t < nt; t++)
-            th.emplace_back([&, t] {
-                for (size_t i = nl * t / nt, e = nl * (t + 1) / nt; i < e; i++) rr[i] = make_uint2(img.leaf_r1[i], img.leaf_r2[i]);
-            });
-        for (auto &x : th) x.join();
-        if (nl) CQ_HIP(upload_array(ix->d_leaf_rids, rr.get(), nl * sizeof(uint2)));
-    }
+    CQ_HIP(upload_array(ix->d_nodes, img.nodes.data(), nb));
+    up_lap("table + nodes");
+    // leaf refIDs: (refID1, refID2) pairs interleaved straight into the page-locked pieces (no 8-byte-per-leaf staging array)
+    CQ_HIP(upload_pieces(ix->d_leaf_rids, nullptr, nl * sizeof(uint2), [&img](char *p, size_t off, size_t n) {
+        uint2 *o = (uint2 *)p;
+        const size_t i0 = off / sizeof(uint2), cnt = n / sizeof(uint2);
+        for (size_t i = 0; i < cnt; i++) o[i] = make_uint2(img.leaf_r1[i0 + i], img.leaf_r2[i0 + i]);
+    }));
+    up_lap("leaf refIDs");
     CQ_HIP(hipMalloc((void **)&ix->d_ovf_count, sizeof(uint32_t)));
     CQ_HIP(hipMalloc((void **)&ix->d_stamps, 8 * sizeof(uint64_t)));
     CQ_HIP(hipMemset(ix->d_stamps, 0, 8 * sizeof(uint64_t)));

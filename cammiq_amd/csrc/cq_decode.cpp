@@ -259,7 +259,6 @@ int decode_table(const std::string &path, DecodedTable &out, std::string &err)
     if (tenv) nt = (unsigned)std::max(1, atoi(tenv));
     Mapped fi, fa;
     const bool opened = nt > 1 && fi.open(path) && fa.open(path + ".aux");
-    if (opened && !tenv && fi.n >= (4ull << 30)) nt = std::max(1u, std::min(std::thread::hardware_concurrency(), 64u));   // multi-GB streams: up to 64 workers
     if (opened && fa.n >= 2 && (getenv("CAMMIQ_DECODE_STEP") || fi.n >= (64u << 20))) {
         const uint32_t doubly = fa.p[0] >> 7, option = fa.p[0] & 127u, h = fa.p[1];
         if (option == 64 && h >= 1 && h <= 31) {

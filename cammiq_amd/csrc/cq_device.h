@@ -133,10 +133,12 @@ CQ_HD uint32_t cq_phi_wide(uint64_t c)
     uint32_t x = lo * 0x9E3779B1u + hi * 0x85EBCBu;
     x ^= x >> 15;
     const uint32_t e2 = (lo * 0xC2B2AE35u + hi * 0x27D4EBu) >> 30;
-    if (x < (1u << 29)) return (x << 2) | e2;
-    if (x < (1u << 30)) return (1u << 31) + ((x - (1u << 29)) << 1) + (e2 >> 1);
-    if (x < (1u << 31)) return (1u << 31) + (1u << 30) + ((x - (1u << 30)) >> 1);
-    return (1u << 31) + (1u << 30) + (1u << 29) + ((x - (1u << 31)) >> 2);
+    /* the four segments, each with its offset folded in (branch-free: data-dependent branches cost the host's layout
+     * pass three times the arithmetic): [0, 2^29) -> 4x + e2; [2^29, 2^30) -> 2^31 + 2(x - 2^29) + e2/2;
+     * [2^30, 2^31) -> 3 2^30 + (x - 2^30)/2; [2^31, 2^32) -> 7 2^29 + (x - 2^31)/4 */
+    const uint32_t s0 = (x << 2) | e2, s1 = 0x40000000u + (x << 1) + (e2 >> 1), s2 = 0xA0000000u + (x >> 1), s3 = 0xC0000000u + (x >> 2);
+    const uint32_t z = x >> 29;
+    return z == 0 ? s0 : z == 1 ? s1 : z < 4 ? s2 : s3;
 }
 
 CQ_HD uint32_t cq_mmer_phi_wide(uint64_t f, uint32_t m)

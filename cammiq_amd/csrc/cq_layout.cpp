@@ -101,7 +101,7 @@ unsigned worker_count(size_t n_items)
 {
     if (const char *v = getenv("CAMMIQ_LAYOUT_THREADS")) return (unsigned)std::max(1, atoi(v));   // tests: 1 = serial
     unsigned hw = std::thread::hardware_concurrency();
-    return n_items < (1u << 16) ? 1u : std::max(1u, std::min(hw ? hw : 1u, n_items >= (1u << 27) ? 64u : 32u));   // 10^8+ items: up to 64 workers
+    return n_items < (1u << 16) ? 1u : std::max(1u, std::min(hw ? hw : 1u, 32u));   // (64 workers measured at 1.26e9 keys: no faster)
 }
 
 template <class F>
