@@ -46,6 +46,21 @@ def mem_available_bytes() -> int:
     return 0
 
 
+def disk_usage_free(d: str) -> int:
+    try:
+        return shutil.disk_usage(d).free
+    except OSError:
+        return 0
+
+
+def scratch_dir() -> str:
+    """Where the index files go: /dev/shm, unless the temporary directory has more room (a container with a tiny shm)."""
+    shm, tmp = "/dev/shm", tempfile.gettempdir()
+    if os.path.isdir(shm) and disk_usage_free(shm) >= disk_usage_free(tmp):
+        return shm
+    return tmp
+
+
 def peak_rss_gb() -> float:
     return resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1e6
 
@@ -56,7 +71,7 @@ def size_for_this_box(genomes: int, want_len: int, host_budget_bytes: float | No
     if shm_bytes is not None:
         shm = shm_bytes
     else:
-        shm = shutil.disk_usage("/dev/shm").free if os.path.isdir("/dev/shm") else avail
+        shm = disk_usage_free(scratch_dir())
     budget = min(0.72 * avail, 260e9)                 # a one-GPU lease is capped at ~270 GiB of host memory
     markers = budget / BYTES_PER_MARKER_HOST_PEAK
     markers = min(markers, 0.8 * shm / 16)            # ~14.8 bytes of index file per marker
@@ -79,8 +94,7 @@ def run(genomes=15000, genome_len=3_450_000, n_reads=20_000_000, rl=150, slice_r
         log(f"[configs4] {name:34s} {time.time() - t0:8.1f} s   peak RSS {peak_rss_gb():6.1f} GB   t+{time.time() - t_all:6.0f} s")
 
     G, h = genomes, 26
-    shm = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
-    wdir = workdir or tempfile.mkdtemp(prefix="cammiq_cfg4_", dir=shm)
+    wdir = workdir or tempfile.mkdtemp(prefix="cammiq_cfg4_", dir=scratch_dir())
     pu, pd = os.path.join(wdir, "index_u.bin1"), os.path.join(wdir, "index_d.bin2")
     su, sd = os.path.join(wdir, "sub_u.bin1"), os.path.join(wdir, "sub_d.bin2")
     try:
