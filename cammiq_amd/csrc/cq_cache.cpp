@@ -23,7 +23,7 @@ namespace cq {
 
 namespace {
 
-constexpr uint32_t kLayoutRev = 12;   // bump whenever cq_device.h's table / trie / minimizer layout changes
+constexpr uint32_t kLayoutRev = 13;   // bump whenever cq_device.h's table / trie / minimizer layout changes
 
 struct Header {
     char magic[8];              // "CQIMG\0\0\0"

@@ -13,7 +13,10 @@
 #endif
 
 #define CQ_LEAF_BIT 0x80000000u
-#define CQ_CHAIN_BIT 0x40000000u          /* word 0 of a path-compressed trie node: CQ_CHAIN_BIT | length */
+#define CQ_CHAIN_BIT 0x40000000u          /* word 0 of a path-compressed trie node: CQ_CHAIN_BIT | refID << 6 | length */
+#define CQ_CHAIN_RID_SHIFT 6u             /* bits 6..29 of that word: refID1 of the UNIQUE leaf the chain ends at (0: none --
+                                             the chain continues, the leaf is doubly unique, or its refID needs more than 24 bits) */
+#define CQ_CHAIN_RID_MAX 0xFFFFFFu
 #define CQ_INLINE_RID_BIT 0x40000000u     /* slot val_d when ht_d has no such key and val_u is a unique leaf:
                                              CQ_INLINE_RID_BIT | refID1 of that leaf (saves the leaf_rids read) */
 #define CQ_INLINE_PAIR_BIT 0x40000000u    /* slot val_u when ht_u has no such key and val_d is a leaf whose two refIDs

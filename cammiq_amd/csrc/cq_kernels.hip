@@ -208,11 +208,13 @@ __device__ __forceinline__ uint64_t row_bits64(const uint32_t *row, int off)
 // query.cpp:447-450).  A chain node stands for `len` single-child inner nodes: the walk
 // either matches all of its symbols or ends without a leaf, exactly like the symbol-by-symbol
 // loop (inner nodes are never leaves; running out of read inside the chain returns NULL).
+// rid_inline: refID1 of the leaf when the walk ended through a chain node that carries it (a unique leaf), else 0.
 __device__ __forceinline__ uint32_t walk_trie(const DevIndex &ix, uint32_t h, const uint32_t *row, uint32_t len,
-                                              uint32_t code, uint32_t strand, uint32_t p)
+                                              uint32_t code, uint32_t strand, uint32_t p, uint32_t &rid_inline)
 {
     const uint32_t rem = strand ? p : (len - h - p);
     uint32_t j = 0;
+    rid_inline = 0;
     for (;;) {
         if (code & CQ_LEAF_BIT) return code & ~CQ_LEAF_BIT;   // cur->isEnd
         if (j == rem) return 0xFFFFFFFFu;                       // read exhausted on an inner node
@@ -227,11 +229,13 @@ __device__ __forceinline__ uint32_t walk_trie(const DevIndex &ix, uint32_t h, co
             if (syms != label) return 0xFFFFFFFFu;              // some children[index] == NULL
             j += L;
             code = n.w;
+            rid_inline = (n.x >> CQ_CHAIN_RID_SHIFT) & CQ_CHAIN_RID_MAX;   // non-zero only when n.w is a unique leaf
         } else {
             const uint32_t sym = strand ? (3u - row_base(row, p - 1u - j)) : row_base(row, p + h + j);
             const uint32_t c = sym == 0 ? n.x : sym == 1 ? n.y : sym == 2 ? n.z : n.w;
             if (c == 0) return 0xFFFFFFFFu;                      // children[index] == NULL
             code = c;
+            rid_inline = 0;
             j++;
         }
     }
@@ -268,8 +272,10 @@ template <int CAP>
 __device__ __forceinline__ void resolve(const DevIndex &ix, uint32_t h, const Tile &t, const uint32_t *row, uint32_t len,
                                         uint32_t rl, uint32_t code, uint32_t strand, uint32_t p)
 {
-    const uint32_t gid = walk_trie(ix, h, row, len, code, strand, p);
+    uint32_t rid_inline;
+    const uint32_t gid = walk_trie(ix, h, row, len, code, strand, p, rid_inline);
     if (gid != 0xFFFFFFFFu) {
+        if (rid_inline) { append_hit<CAP>(t, rl, gid, rid_inline, 0u); return; }   // the chain node brought the refID along
         const uint2 rr = ix.leaf_rids[gid];
         append_hit<CAP>(t, rl, gid, rr.x, rr.y);
     }

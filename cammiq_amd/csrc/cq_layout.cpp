@@ -168,6 +168,7 @@ std::unique_ptr<Entry[]> sort_entries(std::unique_ptr<Entry[]> &e, size_t n, uin
 struct Compressor {
     const std::vector<Node> &in;
     std::vector<Node> &out;
+    const uint32_t *r1, *r2;   // refIDs by global leaf id: a chain that ends at a unique leaf carries the refID inline
     uint32_t run(uint32_t code)
     {
         if (code == 0 || (code & CQ_LEAF_BIT)) return code;
@@ -194,7 +195,15 @@ struct Compressor {
                 const uint32_t nxt = n.child[only];
                 const bool leaf = (nxt & CQ_LEAF_BIT) != 0;
                 if (len == 32 || leaf) { push_chain(len, label); len = 0; label = 0; }
-                if (leaf) { set_link(nxt); return head; }
+                if (leaf) {
+                    set_link(nxt);
+                    // the usual deep key: alone below its bucket, one chain, then its leaf.  A unique leaf's refID rides in the
+                    // chain node's spare bits (cq_device.h CQ_CHAIN_RID_*): the walk ends without the leaf_rids read, one
+                    // dependent HBM round trip less on the exact path
+                    const uint32_t g = nxt & ~CQ_LEAF_BIT;
+                    if (r1 && r2[g] == 0 && r1[g] != 0 && r1[g] <= CQ_CHAIN_RID_MAX) out[(size_t)link].child[0] |= r1[g] << CQ_CHAIN_RID_SHIFT;
+                    return head;
+                }
                 cur = nxt;
                 continue;
             }
@@ -317,7 +326,7 @@ int build_image(const DecodedTable &u, const DecodedTable &d, double keys_per_bu
         std::vector<std::vector<Node>> local(nte);
         parallel_for(nte, [&](unsigned t) {
             local[t].push_back(Node{{0, 0, 0, 0}});
-            Compressor comp{linked, local[t]};
+            Compressor comp{linked, local[t], img.leaf_r1.data(), img.leaf_r2.data()};
             for (uint64_t i : deep[t]) {
                 if (i < nb_u) ent[i].val_u = comp.run(ent[i].val_u);
                 else ent[i].val_d = comp.run(ent[i].val_d);
