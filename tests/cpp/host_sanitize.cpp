@@ -26,6 +26,9 @@ int main(int argc, char **argv)
         rc = cq::decode_table(argv[2], d, err);
         if (rc != CQ_OK) { printf("decode_d %d %s\n", rc, err.c_str()); return 0; }
     } else cq::make_empty_table(u.hash_len, d);
+    // the layout's choice of the minimizer length (cq_device.h): 16-mers below 2.5e8 keys, 18-mers from there on, never longer than h
+    if (cq_choose_minimizer_len(26, 249999999ull) != 16 || cq_choose_minimizer_len(26, 250000000ull) != 18 ||
+        cq_choose_minimizer_len(12, 1ull << 40) != 12 || cq_choose_minimizer_len(17, 1ull << 40) != 17) { printf("MINIMIZER CHOICE\n"); return 1; }
     cq::FlatImage img;
     uint64_t found = 0;
     // the table addressed by 18-mer minimizers (large tables; 64-bit m-mers), then by the automatic choice
