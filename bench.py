@@ -126,6 +126,8 @@ def main():
         # control plane only (id, barriers, max over ranks): gloo on the CPU.  torch's bundled RCCL is never brought
         # up, so the product's collective is the one RCCL instance in the process.
         import torch.distributed as tdist
+        if os.environ.get("MASTER_ADDR", "127.0.0.1") in ("127.0.0.1", "localhost"):
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")   # one node: bind the loopback, the box's hostname may not resolve
         tdist.init_process_group("gloo")
 
     h = k = 26
