@@ -67,6 +67,28 @@ def workload_key(G, genome_len, both, n, rl):
     return f"G{G}_L{genome_len}_{'both' if both else 'unique'}_n{n}_rl{rl}"
 
 
+STAGES = ("started", "index_loaded", "reads_resident", "comm_ready", "preflight_ok", "timed_done", "done")
+
+
+def stage(name: str) -> None:
+    """A rank says how far it got: one line on stderr and -- under bench.py's own launcher -- one file per rank in
+    CAMMIQ_BENCH_STAGE_DIR, which the launcher's per-stage deadline watches (self_launch).  CAMMIQ_BENCH_TEST_STALL=
+    "rank:stage:seconds" makes that rank ("*": every rank) sleep when it reaches that stage (test hook for the deadline)."""
+    r = os.environ.get("RANK", "0")
+    print(f"[bench rank {r}] stage={name}", file=sys.stderr, flush=True)
+    d = os.environ.get("CAMMIQ_BENCH_STAGE_DIR")
+    if d:
+        tmp = os.path.join(d, f".rank_{r}.tmp")
+        with open(tmp, "w") as f:
+            f.write(name)
+        os.replace(tmp, os.path.join(d, f"rank_{r}"))
+    stall = os.environ.get("CAMMIQ_BENCH_TEST_STALL", "")
+    if stall:
+        sr, ss, sec = stall.split(":")
+        if sr in (r, "*") and ss == name:
+            time.sleep(float(sec))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -109,6 +131,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     args.gpus = world
+    stage("started")
 
     import torch
     import cammiq_amd as cq
@@ -154,9 +177,15 @@ def main():
         t0 = time.time()
         ix = cq.Index(pu, pd, device=dev)
         t_load = time.time() - t0
+        stage("index_loaded")
         info = ix.info_dict()
         n_vis = torch.cuda.device_count()
-        multi_leg = world == 1 and not args.no_host_fed and (args.multi_leg == "on" or (args.multi_leg == "auto" and n_vis >= 2))
+        # under a profiler the child would inherit the profiler's environment and put its kernels and copies into the
+        # trace (and touch a second GPU): auto skips the leg there and the line says so
+        profiled = any(k.startswith(("ROCP", "ROCPROF", "ROCTRACER")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
+        multi_leg = world == 1 and not args.no_host_fed and (args.multi_leg == "on" or (args.multi_leg == "auto" and n_vis >= 2 and not profiled))
+        multi_leg_skipped = ("running under a profiler" if world == 1 and not args.no_host_fed and args.multi_leg == "auto"
+                             and n_vis >= 2 and profiled else None)
         if local_rank == 0 and world == 1 and not multi_leg and not (args.cpu_sample > 0 and not args.no_cpu_baseline):
             shutil.rmtree(wdir, ignore_errors=True)    # the CPU leg and the multi leg are the only later readers of the files
 
@@ -195,6 +224,7 @@ def main():
         del ascii_buf
         torch.cuda.synchronize()
         t_reads = time.time() - t0
+        stage("reads_resident")
 
         cw = ix.counter_words(G)
         nleaf = nu + nd
@@ -216,6 +246,7 @@ def main():
                 uid = [cq.comm_unique_id() if rank == 0 else None]
                 tdist.broadcast_object_list(uid, src=0)
                 comm = cq.Comm(ix, uid[0], rank, world)
+                stage("comm_ready")
                 # pre-flight: a 16-word block of ones must come back as 16 x world from the library's collective
                 probe_t = torch.ones(16, dtype=torch.int64, device="cuda")
                 probe_r = torch.ones(8, dtype=torch.int32, device="cuda")
@@ -224,6 +255,8 @@ def main():
                 if int(probe_t.sum().item()) != 16 * world or int(probe_r.sum().item()) != 8 * world:
                     raise SystemExit(f"[bench rank {rank}] cq_counts_allreduce pre-flight returned a wrong sum")
                 reduce_how = "cq_counts_allreduce (RCCL in libcammiq_hip.so; control plane: gloo)"
+        if world > 1:
+            stage("preflight_ok")
 
         step_no = [0]
 
@@ -269,6 +302,7 @@ def main():
         finish_query()
         fence()
         dt = time.perf_counter() - t0
+        stage("timed_done")
         if world > 1:
             tmax = torch.tensor([dt], dtype=torch.float64)
             tdist.all_reduce(tmax, op=tdist.ReduceOp.MAX)
@@ -407,6 +441,8 @@ def main():
         #      of a single device.  It runs in a CHILD process with a time limit (tools/multi_leg.py), after everything this
         #      line reports has been measured: RCCL's first contact with two ranks cannot take the headline down with it.
         #      A failure is recorded in the line (and fails the run only when the counts DIFFER), never hidden.
+        if rank == 0 and multi_leg_skipped:
+            result["multi_in_process"] = {"skipped": multi_leg_skipped}
         if rank == 0 and multi_leg:
             import subprocess
             ndev = min(2, n_vis)
@@ -490,6 +526,7 @@ def main():
             print(json.dumps(result), flush=True)
         if comm is not None:
             comm.close()
+        stage("done")
     finally:
         if world > 1:
             tdist.barrier()
@@ -503,33 +540,104 @@ def self_launch(n: int) -> int:
     """`python bench.py --gpus N` without a launcher: start the N ranks as fresh child processes (this process has
     not imported torch or touched the GPU, and never will), rank 0 inherits stdout so its ONE JSON line is this
     program's output; the other ranks' stdout goes to stderr.  Returns the exit status: 0 only if every rank
-    returned 0.  A rank that fails takes the others down (exact PIDs, no patterns)."""
+    returned 0.  A rank that fails takes the others down (exact PIDs, no patterns).
+
+    The launcher has a deadline and a voice: every rank reports the stage it reached (stage()); a rank that stays in
+    one stage longer than CAMMIQ_BENCH_STAGE_TIMEOUT seconds (default 600) -- stuck in ncclCommInitRank, in the gloo
+    rendezvous, in the first collective -- or a run longer than CAMMIQ_BENCH_TIMEOUT in all (default 3000) ends the run:
+    every live rank is terminated by PID, killed after a grace period, the last stage of every rank is printed and
+    the status is non-zero.  SIGTERM / SIGINT to the launcher do the same, so no rank is left holding a GPU.  Ranks
+    are never restarted in place."""
+    import signal
     import socket
     import subprocess
     with socket.socket() as so:
         so.bind(("127.0.0.1", 0))
         port = so.getsockname()[1]
+    stage_limit = float(os.environ.get("CAMMIQ_BENCH_STAGE_TIMEOUT", "600"))
+    total_limit = float(os.environ.get("CAMMIQ_BENCH_TIMEOUT", "3000"))
+    grace = float(os.environ.get("CAMMIQ_BENCH_KILL_GRACE", "5"))
+    sdir = tempfile.mkdtemp(prefix="cammiq_bench_stages_")
     procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC is the only kind this host driver supports (RCCL)
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=None if r == 0 else sys.stderr))
+    got_signal = []
+
+    def on_signal(signo, _frame):
+        got_signal.append(signo)
+
+    old_handlers = {sg: signal.signal(sg, on_signal) for sg in (signal.SIGTERM, signal.SIGINT)}
+
+    def last_stage(r):
+        try:
+            return open(os.path.join(sdir, f"rank_{r}")).read().strip() or "not_started"
+        except OSError:
+            return "not_started"
+
+    def stop_all(why):
+        live = [r for r in range(len(procs)) if procs[r].poll() is None]
+        print(f"[bench launcher] {why}; last stage per rank: "
+              + ", ".join(f"rank {r}: {last_stage(r)}" + ("" if procs[r].poll() is None else f" (exited {procs[r].returncode})")
+                          for r in range(len(procs))), file=sys.stderr, flush=True)
+        for r in live:
+            procs[r].terminate()
+        t_end = time.monotonic() + grace
+        for r in live:
+            try:
+                procs[r].wait(timeout=max(0.0, t_end - time.monotonic()))
+            except subprocess.TimeoutExpired:
+                print(f"[bench launcher] rank {r} (pid {procs[r].pid}) ignored SIGTERM: SIGKILL", file=sys.stderr, flush=True)
+                procs[r].kill()
+                procs[r].wait()
+
     status = 0
-    alive = set(range(n))
-    while alive:
-        for r in sorted(alive):
-            rc = procs[r].poll()
-            if rc is None:
-                continue
-            alive.discard(r)
-            if rc != 0 and status == 0:
-                status = rc if rc > 0 else 1
-                print(f"[bench launcher] rank {r} exited with status {rc}: stopping the other ranks", file=sys.stderr, flush=True)
-                for q in alive:
-                    procs[q].terminate()
-        time.sleep(0.05)
+    try:
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), CAMMIQ_BENCH_STAGE_DIR=sdir)
+            env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC is the only kind this host driver supports (RCCL)
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                          stdout=None if r == 0 else sys.stderr))
+            print(f"[bench launcher] rank {r} pid {procs[r].pid}", file=sys.stderr, flush=True)
+        t_start = time.monotonic()
+        seen = {r: ("not_started", t_start) for r in range(n)}
+        alive = set(range(n))
+        while alive:
+            now = time.monotonic()
+            if got_signal:
+                status = 128 + got_signal[0]
+                stop_all(f"signal {got_signal[0]} received: stopping all ranks")
+                break
+            for r in sorted(alive):
+                rc = procs[r].poll()
+                if rc is None:
+                    st = last_stage(r)
+                    if st != seen[r][0]:
+                        seen[r] = (st, now)
+                    continue
+                alive.discard(r)
+                if rc != 0 and status == 0:
+                    status = rc if rc > 0 else 1
+                    stop_all(f"rank {r} exited with status {rc}: stopping the other ranks")
+                    alive.clear()
+                    break
+            if not alive or status:
+                break
+            stuck = [r for r in sorted(alive) if now - seen[r][1] > stage_limit]
+            if stuck:
+                status = 124
+                stop_all("deadline: " + ", ".join(f"rank {r} spent more than {stage_limit:g} s in stage={seen[r][0]}" for r in stuck))
+                break
+            if now - t_start > total_limit:
+                status = 124
+                stop_all(f"deadline: the run took more than {total_limit:g} s")
+                break
+            time.sleep(0.05)
+    finally:
+        if any(p.poll() is None for p in procs):     # an exception in the loop above: leave nothing behind
+            stop_all("launcher is exiting")
+            status = status or 1
+        for sg, hd in old_handlers.items():
+            signal.signal(sg, hd)
+        shutil.rmtree(sdir, ignore_errors=True)
     return status
 
 

@@ -1258,9 +1258,13 @@ int multi_query(cq_multi *m, int mode, const Feed &f, uint64_t n_reads, uint32_t
         // ---- the exchange step: one sum of the counter block and of rcount over the devices.  Only the host reads
         //      the totals, and it reads device 0's copy: a reduce to that root moves (P-1)/P of the bytes once, where
         //      the all-reduce moves them twice (SURVEY 5 suggests exactly this; CAMMIQ_MULTI_ALLREDUCE=1 restores the
-        //      all-reduce for A/B timing on a multi-GPU node).  cq_counts_allreduce -- one process per GPU, every
-        //      rank wants the totals -- stays an all-reduce.
-        static const bool all_reduce = getenv("CAMMIQ_MULTI_ALLREDUCE") && atoi(getenv("CAMMIQ_MULTI_ALLREDUCE")) != 0;
+        //      all-reduce for A/B timing on a multi-GPU node; read per query, so that one process can time both:
+        //      tools/multi_leg.py does on the first node that shows it two GPUs).  cq_counts_allreduce -- one process
+        //      per GPU, every rank wants the totals -- stays an all-reduce.
+        //      AFTER THE REDUCE ONLY THE ROOT'S COUNTERS ARE TOTALS: the other shards' d_ctr / d_rc hold their partial
+        //      sums (or RCCL scratch).  That is safe because every consumer below reads m->ix[0] and because
+        //      classify_range zeroes d_ctr and d_rc of every shard at the start of every query.
+        const bool all_reduce = getenv("CAMMIQ_MULTI_ALLREDUCE") && atoi(getenv("CAMMIQ_MULTI_ALLREDUCE")) != 0;
         CQ_NCCL(ncclGroupStart());
         ncclResult_t bad = ncclSuccess;
         for (size_t k = 0; k < m->leaders.size(); k++) {

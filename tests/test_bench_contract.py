@@ -89,3 +89,23 @@ def test_two_ranks_rehearsal_over_gloo():
     assert j["n_gpus"] == 2 and "sharded x2" in j["config"]["parallelism"] and "gloo" in j["config"]["parallelism"]
     assert j["outcome"]["reads"] == 2 * 2 * 200000       # both ranks' reads are in the all-reduced counters
     assert "cpu_baseline" not in j                        # rank 0 at N = 1 only
+
+
+def test_a_rank_stuck_past_the_deadline_ends_the_run_with_its_stage():
+    """One rank sleeps past a 5 s per-stage deadline (after its reads are resident, where a hung RCCL bring-up would
+    sit): the launcher stops both ranks by PID, returns 124 and names the stage -- nothing hangs until the harness's
+    own limit, no rank is left on the GPU."""
+    import re
+    env = dict(os.environ, CAMMIQ_BENCH_REHEARSAL="1", CAMMIQ_BENCH_TEST_STALL="1:reads_resident:600",
+               CAMMIQ_BENCH_STAGE_TIMEOUT="5", CAMMIQ_BENCH_KILL_GRACE="3")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + TOY, capture_output=True, text=True,
+                       timeout=300, env=env)
+    assert r.returncode == 124, r.stderr[-2000:]
+    # (rank 0 waits for rank 1 in the next barrier, so whichever entered its stage first trips the deadline)
+    assert "deadline: rank" in r.stderr and "spent more than 5 s in stage=" in r.stderr and "rank 1: reads_resident" in r.stderr, r.stderr[-2000:]
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+    for pid in re.findall(r"\[bench launcher\] rank \d+ pid (\d+)", r.stderr):
+        with pytest.raises(ProcessLookupError):
+            os.kill(int(pid), 0)

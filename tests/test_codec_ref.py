@@ -19,7 +19,20 @@ import oracle_lib
 import pyref
 
 REF_SO = os.path.join(oracle_lib.ORACLE_DIR, "_ref", "libref_binaryio.so")
-pytestmark = pytest.mark.skipif(not os.path.exists(REF_SO), reason="oracle/_ref not built (no /root/reference)")
+REF_SRC = "/root/reference/src/binaryio.cpp"
+
+
+def _ensure_ref_built():
+    """oracle/_ref is built HERE, when this module is imported (pytest collects before any session fixture runs: a
+    skipif evaluated against a file the fixture builds later would silently drop the only reference-pinned layer on
+    a fresh checkout).  The tests skip only where neither the reference's sources nor a prebuilt .so exist."""
+    if not os.path.exists(REF_SO) and os.path.exists(REF_SRC):
+        oracle_lib.build()
+    return os.path.exists(REF_SO)
+
+
+pytestmark = pytest.mark.skipif(not _ensure_ref_built(),
+                                reason="no /root/reference and no prebuilt oracle/_ref/libref_binaryio.so")
 
 
 def _ref():

@@ -47,16 +47,28 @@ def main():
     t_load = time.perf_counter() - t0
     out = mm.shards[0].counts_out(G, pinned=True)
     mm.query_packed_tight(hp[:1 << 16], hl[:1 << 16], rl, G, out=out)
-    ts = []
-    for _ in range(2):
-        t0 = time.perf_counter()
-        mq = mm.query_packed_tight(hp, hl, rl, G, out=out)
-        ts.append(time.perf_counter() - t0)
-    same = all(np.array_equal(mq[k], single[k]) for k in ("cnt_u", "cnt_d", "rcount_u", "rcount_d")) \
-        and mq["nundet"] == single["nundet"] and mq["nconf"] == single["nconf"]
+    def equal(mq):
+        return all(np.array_equal(mq[k], single[k]) for k in ("cnt_u", "cnt_d", "rcount_u", "rcount_d")) \
+            and mq["nundet"] == single["nundet"] and mq["nconf"] == single["nconf"]
+
+    # The exchange step both ways (the library reads CAMMIQ_MULTI_ALLREDUCE per query): the default reduce to the device
+    # the host reads, then the all-reduce.  With one device both are the one-rank communicator; with two or more this is
+    # the A/B nobody could take on a one-GPU lease -- taken automatically by the first run that sees >= 2 GPUs.
+    same, by_kind = True, {}
+    for kind, flag in (("reduce_to_root", "0"), ("all_reduce", "1")):
+        os.environ["CAMMIQ_MULTI_ALLREDUCE"] = flag
+        tk = []
+        for _ in range(2):
+            t0 = time.perf_counter()
+            mq = mm.query_packed_tight(hp, hl, rl, G, out=out)
+            tk.append(time.perf_counter() - t0)
+            same = same and equal(mq)
+        by_kind[kind] = {"ms": round(min(tk) * 1e3, 3), "runs_ms": [round(x * 1e3, 3) for x in tk]}
+    os.environ.pop("CAMMIQ_MULTI_ALLREDUCE", None)
+    ts = [by_kind["reduce_to_root"]["ms"] * 1e-3]
     mm.close()
     print(json.dumps({"devices": devs, "reads": n, "Mreads_s": round(n / min(ts) / 1e6, 2), "ms": round(min(ts) * 1e3, 3),
-                      "equals_single_device": bool(same), "load_s": round(t_load, 2),
+                      "equals_single_device": bool(same), "load_s": round(t_load, 2), "exchange_ab": by_kind,
                       "what": "cq_multi_query_packed_tight in a child process: reads sharded over the devices by "
                               "cq_shard_range, one host thread per device, RCCL reduce of counter block + rcount to the "
                               "device the host reads, inside libcammiq_hip.so"}), flush=True)
