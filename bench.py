@@ -53,9 +53,16 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 GEN_CHUNK = 5_000_000  # reads generated + packed per piece (one reusable ASCII buffer)
 
 PRESETS = {
-    1: dict(genomes=500, both=False, reads=10_000_000, label="configs[1]"),
-    2: dict(genomes=1000, both=True, reads=50_000_000, label="configs[2]"),
+    1: dict(genomes=500, both=False, reads=10_000_000, read_len=100, batches=3, label="configs[1]"),
+    2: dict(genomes=1000, both=True, reads=50_000_000, read_len=100, batches=3, label="configs[2]"),
+    # configs[4]'s per-GPU shard: ~15 000 genomes, --both index "sized to 288 GB HBM", 1 B x 150 bp reads over 8 GPUs = 125 M
+    # per GPU.  The index is as large as THIS box's host can build (tools/configs4.py size_for_this_box: 15 000 x 3.45 Mbp =
+    # 1.26e9 markers where the host has the memory, shorter genomes where it has not -- the line says which); one
+    # resident batch; the CPU leg and the parity gate run on a slice against the generator's sub-index (the oracle cannot
+    # hold 10^9 markers: tests/test_subindex.py proves the construction).
+    4: dict(genomes=15000, both=True, reads=125_000_000, read_len=150, batches=1, label="configs[4] per-GPU shard"),
 }
+BIG_INDEX_MARKERS = 3e8   # beyond: the oracle works on the sub-index of its slice
 
 
 def algorithmic_bytes_per_read(rl: int, h: int, tables: int) -> int:
@@ -97,10 +104,11 @@ def main():
     ap.add_argument("--config", type=int, default=2, choices=sorted(PRESETS),
                     help="BASELINE.json configs[i]: 2 = 1000 genomes, --both, 50 M reads (default); 1 = 500, --unique, 10 M")
     ap.add_argument("--genomes", type=int, default=None)
-    ap.add_argument("--genome-len", type=int, default=3_450_000)
+    ap.add_argument("--genome-len", type=int, default=None,
+                    help="default 3 450 000; --config 4: the largest up to that whose index this box's host memory can build")
     ap.add_argument("--reads", type=int, default=None, help="reads per GPU per step")
-    ap.add_argument("--read-len", type=int, default=100)
-    ap.add_argument("--batches", type=int, default=3, help="distinct resident batches the steps rotate over")
+    ap.add_argument("--read-len", type=int, default=None, help="default: the preset's (100; 150 for --config 4)")
+    ap.add_argument("--batches", type=int, default=None, help="distinct resident batches the steps rotate over (default 3; 1 for --config 4)")
     ap.add_argument("--frac-deep", type=float, default=0.07,
                     help="fraction of markers longer than k (trie depth > 0); 0.07 is what the survey measured")
     ap.add_argument("--both", action="store_true", default=None, help="unique + doubly-unique index")
@@ -110,6 +118,7 @@ def main():
                     help="skip the CPU oracle leg and its parity gate (used under rocprofv3 so that every "
                          "classify launch in the trace is a full-size timed step)")
     ap.add_argument("--no-host-fed", action="store_true", help="skip the PCIe-inclusive leg (cq_query_packed)")
+    ap.add_argument("--no-calibrate", action="store_true", help="skip the board calibrators (cq_calibrate, ~1 s before the timed region)")
     ap.add_argument("--multi-leg", choices=["auto", "on", "off"], default="auto",
                     help="N = 1 only: also run the same host-fed query through cq_multi_load / cq_multi_query_packed_tight (one "
                          "process, one host thread per GPU, RCCL inside the library) on min(2, visible GPUs) devices and "
@@ -121,9 +130,25 @@ def main():
     G = args.genomes if args.genomes is not None else preset["genomes"]
     both = preset["both"] if args.both is None else args.both
     n = args.reads if args.reads is not None else preset["reads"]
-    is_preset = (G == preset["genomes"] and both == preset["both"] and n == preset["reads"] and args.read_len == 100
+    if args.read_len is None:
+        args.read_len = preset["read_len"]
+    if args.batches is None:
+        args.batches = preset["batches"]
+    fitted = None
+    if args.genome_len is None:
+        args.genome_len = 3_450_000
+        if args.config == 4:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import configs4
+            args.genome_len, avail, shm_free = configs4.size_for_this_box(G, 3_450_000)
+            fitted = f"host: {avail / 1e9:.0f} GB available, {shm_free / 1e9:.0f} GB of scratch -> genome length {args.genome_len} of 3450000"
+            if "WORLD_SIZE" not in os.environ or os.environ.get("RANK", "0") == "0":
+                print(f"[bench] --config 4: {fitted}", file=sys.stderr, flush=True)
+    is_preset = (G == preset["genomes"] and both == preset["both"] and n == preset["reads"] and args.read_len == preset["read_len"]
                  and args.genome_len == 3_450_000)
     label = preset["label"] if is_preset else f"configs[{args.config}]-shape (modified)"
+    if args.config == 4 and fitted and args.genome_len != 3_450_000:
+        label = f"configs[4] per-GPU shard, index shortened to what this host can build ({args.genome_len}-bp genomes)"
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         raise SystemExit(self_launch(args.gpus))      # nothing below has run yet: no torch import, no GPU touched
@@ -165,9 +190,27 @@ def main():
                            frac_deep=args.frac_deep, pair_share=0.3 if both else 0.0)
         pu = os.path.join(wdir, "index_u.bin1")
         pd = os.path.join(wdir, "index_d.bin2") if both else None
+        # an index the oracle cannot hold (configs[4]: ~100 bytes of heap per trie node): the generator also writes the
+        # SUB-INDEX of the slice the CPU leg will see -- exactly the full index's markers whose h-mer occurs in those
+        # reads -- and each of its leaves' position in the full index's decode order (tools/configs4.py, tests/test_subindex.py)
+        est_markers = G * args.genome_len * (2 / 69 * 0.839) * (1.0 if both else 0.82)
+        big = est_markers > BIG_INDEX_MARKERS
+        want_cpu = rank == 0 and world == 1 and args.cpu_sample > 0 and not args.no_cpu_baseline
+        su = os.path.join(wdir, "sub_u.bin1")
+        sd = os.path.join(wdir, "sub_d.bin2") if both else None
+        sub_ids = None
         if local_rank == 0:
             os.makedirs(wdir, exist_ok=True)
-            nu, nd = w.write_index(pu, pd)
+            if big and want_cpu:
+                sys.path.insert(0, os.path.join(ROOT, "tests"))
+                from util import hmers_of_reads
+                args.cpu_sample = min(args.cpu_sample, 100_000, n)
+                sl_b, _ = w.reads(seed=1000 + 16 * rank, n=args.cpu_sample, length=args.read_len)
+                nu, nd, ids_u, ids_d = w.write_index_with_sub(pu, pd, hmers_of_reads(sl_b, args.cpu_sample, args.read_len, h), su, sd)
+                sub_ids = (ids_u, ids_d)
+                del sl_b
+            else:
+                nu, nd = w.write_index(pu, pd)
             with open(os.path.join(wdir, "leaves.txt"), "w") as f:
                 f.write(f"{nu} {nd}\n")
         if world > 1:
@@ -188,6 +231,10 @@ def main():
                              and n_vis >= 2 and profiled else None)
         if local_rank == 0 and world == 1 and not multi_leg and not (args.cpu_sample > 0 and not args.no_cpu_baseline):
             shutil.rmtree(wdir, ignore_errors=True)    # the CPU leg and the multi leg are the only later readers of the files
+        elif local_rank == 0 and world == 1 and big and not multi_leg:
+            for f in (pu, pu + ".aux", pd, (pd or "") + ".aux"):   # ~19 GB of /dev/shm at configs[4]: only the sub-index is read again
+                if f and os.path.exists(f):
+                    os.unlink(f)
 
         # ---- the batches: generated piecewise, packed once, resident in HBM (and, for the host-fed leg, in
         #      page-locked host memory).  Batch j of rank r is read stream 1000 + 16 r + j of the generator.
@@ -257,6 +304,16 @@ def main():
                 reduce_how = "cq_counts_allreduce (RCCL in libcammiq_hip.so; control plane: gloo)"
         if world > 1:
             stage("preflight_ok")
+
+        # ---- what THIS board gives the kernel to work with, before the timed region (cq_calibrate, ~1 s): the chip's rate
+        #      of random 16-byte loads from the handle's own table, the same with atomics + LDS traffic beside the loads,
+        #      and the shader clock held under both -- so that the line itself says whether a slow run was the board
+        calib = None
+        if rank == 0 and not args.no_calibrate:
+            try:
+                calib = ix.calibrate()
+            except Exception as e:       # diagnostic only: never takes the measurement down
+                calib = {"error": str(e)[:200]}
 
         step_no = [0]
 
@@ -348,7 +405,7 @@ def main():
             # measured HBM traffic + gather ceiling of this exact workload, from the committed PMC passes
             key = workload_key(G, args.genome_len, both, n, rl)
             ent = None
-            for tp in ("traffic_r03.json", "traffic_r02.json"):   # the newest round that profiled this workload
+            for tp in ("traffic_r04.json", "traffic_r03.json", "traffic_r02.json"):   # the newest round that profiled this workload
                 tp = os.path.join(ROOT, "profiles", tp)
                 if ent is None and os.path.exists(tp):
                     try:
@@ -375,6 +432,24 @@ def main():
                     lines = float(ent.get("fetch_bytes_per_launch", hb)) / 64.0 / (k_ms * 1e-3)
                     roof["gather_ceiling_frac"] = round(lines / float(ent["gather_ceiling_lines_per_s"]), 5)
                     roof["gather_ceiling_note"] = ent.get("gather_ceiling_note")
+            if calib and "error" not in calib:
+                roof["board"] = {
+                    "gather_ceiling_here_Glines_s": round(calib["gather16_Glines_s"], 3),
+                    "gather_mix_here_Glines_s": round(calib["gather16_mix_Glines_s"], 3),
+                    "shader_clock_MHz_gather": round(calib["clock_MHz_gather"], 1),
+                    "shader_clock_MHz_mix": round(calib["clock_MHz_mix"], 1),
+                    "blocks_per_cu_best": [calib["gather_blocks_per_cu"], calib["mix_blocks_per_cu"]],
+                    "table_GB": round(calib["table_bytes"] / 1e9, 3), "seconds": round(calib["seconds"], 2),
+                    "what": "cq_calibrate on this run's board, before the timed region: random 16-byte loads from the "
+                            "handle's own table (4 in flight per lane, best of 4/6/8 workgroups per CU); mix = the same "
+                            "with a returnless atomic per 16 loads into an rcount-sized array and LDS stores/reads beside "
+                            "them; clocks = shader cycles per 100 MHz tick inside those kernels (median over workgroups)"}
+                if ent and ent.get("fetch_bytes_per_launch"):
+                    lines = float(ent["fetch_bytes_per_launch"]) / 64.0 / (k_ms * 1e-3)
+                    roof["gather_ceiling_frac_here"] = round(lines / (calib["gather16_Glines_s"] * 1e9), 5)
+                    roof["gather_mix_frac_here"] = round(lines / (calib["gather16_mix_Glines_s"] * 1e9), 5)
+            elif calib:
+                roof["board"] = calib
             result = {
                 "metric": METRIC, "value": round(value, 3), "unit": "Mreads/s", "n_gpus": world,
                 "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
@@ -413,7 +488,7 @@ def main():
                 hq = ix.query_packed_tight(h_packed[0], h_lens[0], rl, G, out=out)
                 ts.append(time.perf_counter() - t0)
             th = min(ts)
-            row_bytes = sb + 1
+            row_bytes = sb        # every read of the batch has one length: the lengths are filled on the device, not sent (else sb + 1)
             # SURVEY.md 8(d) defines the metric's bracket as H2D of packed reads + kernels + D2H: that number is this one
             # (`value` is the task contract's HBM-resident rate); quote both whenever one is quoted
             result["value_survey_8d_bracket"] = round(n / th / 1e6, 2)
@@ -422,8 +497,10 @@ def main():
                 "rows_over_bracket_GBs": round(n * row_bytes / th / 1e9, 2), "bytes_per_read_on_the_wire": row_bytes,
                 "what": "cq_query_packed_tight: tight 2-bit rows (ceil(len/4) bytes) in pinned host memory -> H2D in 2 M-read "
                         "chunks on a copy stream, widened to word rows on the device and classified while the next chunk "
-                        "arrives -> D2H of the counter block and of rcount into pinned "
-                        "memory (SURVEY 8(d) bracket, = the reference's Time-for-query bracket); best of 3"}
+                        "arrives (lengths of a uniform-length chunk are filled on the device, not sent) -> D2H of the counter "
+                        "block; rcount comes back as one byte per leaf + an escape list and is widened into the caller's pinned "
+                        "uint32 arrays by host threads while later pieces arrive (SURVEY 8(d) bracket, = the reference's "
+                        "Time-for-query bracket); best of 3"}
             # one query of batch 0 alone must agree with itself through both doors
             ctr.zero_(); rcd.zero_()
             ix.query_device(cq.MODE_P, d_packed[0].data_ptr(), d_lens[0].data_ptr(), n, sw, rl, G, ctr.data_ptr(),
@@ -434,7 +511,9 @@ def main():
                 "host-fed path disagrees with the device path"
             assert int(c0[2 * G + 2]) == hq["nundet"] and int(c0[2 * G + 3]) == hq["nconf"]
             if nleaf:
-                assert np.array_equal(rcd.cpu().numpy().view(np.uint32)[:nu], hq["rcount_u"])
+                rc_dev = rcd.cpu().numpy().view(np.uint32)
+                assert np.array_equal(rc_dev[:nu], hq["rcount_u"]) and np.array_equal(rc_dev[nu:nu + nd], hq["rcount_d"]), \
+                    "rcount through the host-fed door (narrow over the link, widened on the host) differs from the device's"
 
         # ---- second N > 1 shape: ONE process, one host thread per GPU inside the library, the library's
         #      own RCCL reduction -- the same kind of host-fed query over min(2, visible GPUs) devices must give the counts
@@ -480,7 +559,7 @@ def main():
             except AttributeError:
                 cores = os.cpu_count() or 1
             cores = max(1, min(cores, oracle_lib.lib().cqo_omp_max_threads() if not os.environ.get("OMP_NUM_THREADS") else cores))
-            oi = oracle_lib.OracleIndex(pu, pd)
+            oi = oracle_lib.OracleIndex(su, sd) if big else oracle_lib.OracleIndex(pu, pd)
             sb, so = sample_bases, np.arange(ns + 1, dtype=np.uint64) * np.uint64(rl)
             keys4 = ("cnt_u", "cnt_d", "rcount_u", "rcount_d")
             # ~25 s of CPU work in all: the thread-local and the atomic variant on the whole sample, the locked one (which
@@ -493,32 +572,57 @@ def main():
             tt = ref["loop_s"]
             fair = oi.query(sb, so, G, mode=0, nthreads=cores, variant="atomic")        # the locked loop with atomics instead
             tf = fair["loop_s"]
-            nsl = ns if cores <= 32 else max(ns // 4, 1)
-            lk = oi.query(sb[:nsl * rl], so[:nsl + 1], G, mode=0, nthreads=cores, variant="critical")   # query64mt_p as written
-            tc = lk["loop_s"]
+            # query64mt_p as written (one global critical section per read, query.cpp:742-878) gets SLOWER with many
+            # threads; a reference user picks -t, so the faithful figure is its best over a few thread counts -- on a
+            # quarter of the sample, every run's counters compared with a thread-local run of the same quarter
+            nsl = max(ns // 4, 1)
+            refq = ref if nsl == ns else oi.query(sb[:nsl * rl], so[:nsl + 1], G, mode=0, nthreads=cores, variant="thread_local")
             assert all(np.array_equal(fair[kk], ref[kk]) for kk in keys4) and fair["nundet"] == ref["nundet"] \
                 and fair["nconf"] == ref["nconf"], "CPU variant atomic differs from the thread-local one"
-            if nsl == ns:
-                assert all(np.array_equal(lk[kk], ref[kk]) for kk in keys4), "CPU variant critical differs from the thread-local one"
+            crit = {}
+            for t in sorted({x for x in (8, 16, 32, cores) if x <= cores}):
+                lk = oi.query(sb[:nsl * rl], so[:nsl + 1], G, mode=0, nthreads=t, variant="critical")
+                assert all(np.array_equal(lk[kk], refq[kk]) for kk in keys4) and lk["nundet"] == refq["nundet"] \
+                    and lk["nconf"] == refq["nconf"], f"CPU variant critical ({t} threads) differs from the thread-local one"
+                crit[t] = nsl / lk["loop_s"] / 1e6
             ns1 = max(ns // 8, 1)
             tc1 = oi.query(sb[:ns1 * rl], so[:ns1 + 1], G, mode=0, nthreads=1)["loop_s"]
+            crit[1] = ns1 / tc1 / 1e6
+            best_t = max(crit, key=crit.get)
             t_cpu = time.perf_counter() - t_cpu0
             # parity gate on the very same sample, through the product's host API
             got = ix.query(sb, so, G)
-            parity = all(np.array_equal(got[kk], ref[kk]) for kk in keys4) \
-                and got["nundet"] == ref["nundet"] and got["nconf"] == ref["nconf"]
+            if big:
+                # the oracle saw the sub-index: its rcount belongs at the sub-index leaves' positions in the full index's
+                # decode order, every other leaf of the full index must read zero
+                parity = all(np.array_equal(got[kk], ref[kk]) for kk in ("cnt_u", "cnt_d"))
+                for kk, ids, n_full in (("rcount_u", sub_ids[0], nu), ("rcount_d", sub_ids[1], nd)):
+                    exp = np.zeros(n_full, np.uint32)
+                    exp[ids.astype(np.int64)] = ref[kk]
+                    parity = parity and np.array_equal(got[kk], exp)
+                    del exp
+            else:
+                parity = all(np.array_equal(got[kk], ref[kk]) for kk in keys4)
+            parity = parity and got["nundet"] == ref["nundet"] and got["nconf"] == ref["nconf"]
             if not parity:
                 raise SystemExit("PARITY FAILURE: GPU counters differ from the CPU oracle on the bench sample")
             result["cpu_baseline"] = {
-                "value": round(nsl / tc / 1e6, 4), "unit": "Mreads/s", "cores": cores, "kind": "port",
+                "value": round(crit[best_t], 4), "unit": "Mreads/s", "cores": best_t, "kind": "port",
+                "value_as_written_by_threads": {str(t): round(v, 4) for t, v in sorted(crit.items())},
                 "value_thread_local": round(ns / tt / 1e6, 4), "value_atomic": round(ns / tf / 1e6, 4),
-                "value_one_core": round(ns1 / tc1 / 1e6, 4),
-                "host_cores_online": os.cpu_count(),
-                "sample": f"first {ns} reads of batch 0, same index, {cores} OpenMP threads = every core this process may "
-                          f"use ({os.cpu_count()} online on the box). value: OpenMP over reads with one global critical "
-                          f"section per read as query64mt_p (oracle/cammiq_oracle.c), on the first {nsl} reads; value_thread_local: per-thread "
-                          f"counters merged after the loop, rcount by atomics (SURVEY 8(d)'s optimised variant); "
-                          f"value_atomic: the locked loop with atomics instead; value_one_core: serial, {ns1} reads",
+                "value_one_core": round(crit[1], 4), "best_value": round(max(ns / tt / 1e6, ns / tf / 1e6, crit[best_t]), 4),
+                "cores_available": cores, "host_cores_online": os.cpu_count(),
+                "sample": ("ORACLE ON THE SUB-INDEX of its slice (the full index's markers whose h-mer occurs in these reads: same "
+                           "answers, a far smaller map -- the CPU rates are an UPPER bound of what the full index would give). "
+                           if big else "") +
+                          f"first {ns} reads of batch 0, same index; {cores} cores available to this process "
+                          f"({os.cpu_count()} online on the box). value: OpenMP over reads with one global critical "
+                          f"section per read as query64mt_p (oracle/cammiq_oracle.c), best over "
+                          f"{sorted(crit)} threads (`cores` = the best count) on the first {nsl} reads ({ns1} for one "
+                          f"thread), every run equal to the thread-local counters; value_thread_local: per-thread "
+                          f"counters merged after the loop, rcount by atomics, {cores} threads, all {ns} reads (SURVEY 8(d)'s "
+                          f"optimised variant -- the number to hold the GPU against, = best_value when it is the fastest); "
+                          f"value_atomic: the locked loop with atomics instead, {cores} threads",
                 "bracket": "the loop over the reads alone, as the reference's Time for query (query.cpp:459,645-647)",
                 "cpu_model": _cpu_model(), "seconds": round(t_cpu, 2)}
             result["parity_checked_reads"] = ns

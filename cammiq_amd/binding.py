@@ -39,6 +39,12 @@ class _LaunchInfo(C.Structure):
                 ("blocks_per_cu", C.c_int32), ("minimizer_len", C.c_int32)]
 
 
+class _Calibration(C.Structure):
+    _fields_ = [("gather16_Glines_s", C.c_double), ("gather16_mix_Glines_s", C.c_double), ("clock_MHz_gather", C.c_double),
+                ("clock_MHz_mix", C.c_double), ("table_bytes", C.c_double), ("seconds", C.c_double),
+                ("gather_blocks_per_cu", C.c_int32), ("mix_blocks_per_cu", C.c_int32)]
+
+
 class _Counts(C.Structure):
     _fields_ = [("cnt_u", C.c_void_p), ("cnt_d", C.c_void_p), ("rcount_u", C.c_void_p),
                 ("rcount_d", C.c_void_p), ("nundet", C.c_uint64), ("nconf", C.c_uint64),
@@ -83,6 +89,7 @@ SIGNATURES = {
                                         C.c_uint32, C.c_uint32, C.POINTER(_Counts)]),
     "cq_multi_query_packed_tight": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32,
                                               C.c_uint32, C.c_uint32, C.POINTER(_Counts)]),
+    "cq_calibrate": (C.c_int, [C.c_void_p, C.c_void_p]),
     "cq_host_alloc": (C.c_int, [C.POINTER(C.c_void_p), C.c_size_t]),
     "cq_host_free": (None, [C.c_void_p]),
     "cq_pairs_reserve": (C.c_int, [C.c_void_p, C.c_uint64]),
@@ -320,6 +327,12 @@ class Index:
         fx = f",{d['fixed_hash_len']},{d['fixed_read_len']},{d['minimizer_len']}" if d["fixed_shape"] else ",0,0,0"
         d["kernel"] = f"classify_kernel<{d['reads_per_subtile']},{d['hit_slots']},false{fx}>"
         return d
+
+    def calibrate(self) -> dict:
+        """cq_calibrate: this board's random-load ceiling on the handle's own table and the clock it holds (diagnostic)."""
+        c = _Calibration()
+        _check(lib().cq_calibrate(self._h, C.byref(c)))
+        return {k: (int(getattr(c, k)) if k.endswith("per_cu") else float(getattr(c, k))) for k, _ in _Calibration._fields_}
 
     def pairs_reserve(self, n_slots: int):
         _check(lib().cq_pairs_reserve(self._h, n_slots))

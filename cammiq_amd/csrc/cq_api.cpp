@@ -13,10 +13,14 @@
 // ncclCommInitAll) and cq_comm_* (one process per GPU, ncclCommInitRank).
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <functional>
 #include <map>
 #include <memory>
+#include <mutex>
+#include <immintrin.h>
 
 #include <cstdarg>
 #include <cstdio>
@@ -56,12 +60,152 @@ int fail(int code, const std::string &msg)
     } while (0)
 
 constexpr uint32_t kPairCapDefault = 1u << 20;   // slots of the SC-mode pair map (grown on demand)
-const uint64_t kChunk = [] {                     // reads per pipelined chunk of the host-fed paths (CAMMIQ_CHUNK_READS: tuning knob)
+constexpr uint64_t kChunk = 1ull << 21;          // reads per pipelined chunk of the host-fed paths (what the workspace is sized for)
+uint64_t chunk_reads()                           // ... CAMMIQ_CHUNK_READS overrides (tuning knob, read per query so that one process can A/B)
+{
     const char *v = getenv("CAMMIQ_CHUNK_READS");
     const unsigned long long n = v ? strtoull(v, nullptr, 10) : 0;
-    return n >= 1024 && n <= (1ull << 28) ? (uint64_t)n : (1ull << 21);
-}();
+    return n >= 1024 && n <= (1ull << 28) ? (uint64_t)n : kChunk;
+}
 constexpr size_t kBounce = 16u << 20;            // pinned bounce buffer for D2H into pageable arrays
+constexpr int kSlots = 4;                        // staging slots of the host-fed pipeline
+// rcount comes back narrow (one byte per leaf + escapes, launch_narrow_rcount): pieces of kNarrowPiece bytes rotate over
+// a page-locked ring while a few host threads widen the piece before into the caller's uint32 arrays
+constexpr size_t kNarrowPiece = 4u << 20;
+constexpr int kNarrowRing = 8;
+constexpr uint64_t kNarrowFrom = 1u << 20;       // leaves; below, the plain uint32 copy is a fraction of a millisecond anyway
+
+// bytes -> uint32, entries [0, n): streaming stores where the destination allows (the 4 n bytes written are never
+// read back by these threads, and a widened rcount of configs[2] is 336 MB: it must not go through the caches)
+__attribute__((target("avx2"))) void widen_u8_avx2(const uint8_t *src, uint32_t *dst, size_t n)
+{
+    size_t i = 0;
+    while (i < n && ((uintptr_t)(dst + i) & 31u)) { dst[i] = src[i]; i++; }
+    for (; i + 32 <= n; i += 32) {
+        const __m128i a = _mm_loadu_si128((const __m128i *)(src + i)), b = _mm_loadu_si128((const __m128i *)(src + i + 16));
+        _mm256_stream_si256((__m256i *)(dst + i), _mm256_cvtepu8_epi32(a));
+        _mm256_stream_si256((__m256i *)(dst + i + 8), _mm256_cvtepu8_epi32(_mm_srli_si128(a, 8)));
+        _mm256_stream_si256((__m256i *)(dst + i + 16), _mm256_cvtepu8_epi32(b));
+        _mm256_stream_si256((__m256i *)(dst + i + 24), _mm256_cvtepu8_epi32(_mm_srli_si128(b, 8)));
+    }
+    for (; i < n; i++) dst[i] = src[i];
+    _mm_sfence();
+}
+
+void widen_u8(const uint8_t *src, uint32_t *dst, size_t n)
+{
+    static const bool avx2 = __builtin_cpu_supports("avx2");
+    if (avx2) return widen_u8_avx2(src, dst, n);
+    for (size_t i = 0; i < n; i++) dst[i] = src[i];
+}
+
+// Narrow entries of GLOBAL leaf indices [a, b) (src8[0] = leaf a) into the two caller arrays: leaves below n_u are
+// ht_u's (rcount_u[i]), the rest ht_d's (rcount_d[i - n_u]) -- the device keeps one id space, u first.
+void widen_span(const uint8_t *src8, uint64_t a, uint64_t b, uint64_t n_u, uint32_t *dst_u, uint32_t *dst_d)
+{
+    if (a < n_u) { const uint64_t e = std::min(b, n_u); widen_u8(src8, dst_u + a, (size_t)(e - a)); }
+    if (b > n_u) { const uint64_t s0 = std::max(a, n_u); widen_u8(src8 + (s0 - a), dst_d + (s0 - n_u), (size_t)(b - s0)); }
+}
+
+// A few host threads that sleep between queries and widen the pieces of one narrow rcount as the copy engine
+// delivers them (fetch_rcount_narrow).  Piece k lives in ring slot k % kNarrowRing; `ready` = pieces delivered so far;
+// fin[slot] counts the workers that are through with the piece in that slot, over the whole job.
+struct WidenPool {
+    std::vector<std::thread> th;
+    std::mutex mu;
+    std::condition_variable cv;
+    uint64_t job_seq = 0;
+    bool quit = false;
+    // the current job
+    const uint8_t *ring = nullptr;
+    uint64_t n = 0, n_u = 0, n_pieces = 0, piece = kNarrowPiece;
+    uint32_t *dst_u = nullptr, *dst_d = nullptr;
+    std::atomic<uint64_t> ready{0};
+    std::atomic<uint64_t> fin[kNarrowRing];
+    std::atomic<uint32_t> workers_done{0};
+
+    void run(unsigned t, unsigned W)
+    {
+        uint64_t seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return quit || job_seq != seen; });
+                if (quit) return;
+                seen = job_seq;
+            }
+            for (uint64_t k = 0; k < n_pieces; k++) {
+                while (ready.load(std::memory_order_acquire) <= k) _mm_pause();
+                const uint64_t lo = k * piece, len = std::min<uint64_t>(piece, n - lo);
+                auto cut = [&](unsigned i) { return i >= W ? len : (len * i / W) & ~(uint64_t)63; };   // 64-entry cuts: aligned streaming stores
+                const uint64_t a = cut(t), b = cut(t + 1);
+                if (b > a) widen_span(ring + (k % kNarrowRing) * piece + a, lo + a, lo + b, n_u, dst_u, dst_d);
+                fin[k % kNarrowRing].fetch_add(1, std::memory_order_release);
+            }
+            workers_done.fetch_add(1, std::memory_order_release);
+        }
+    }
+    void start(unsigned W)
+    {
+        for (auto &f : fin) f.store(0);
+        for (unsigned t = 0; t < W; t++) th.emplace_back([this, t, W] { run(t, W); });
+    }
+    void stop()
+    {
+        { std::lock_guard<std::mutex> lk(mu); quit = true; }
+        cv.notify_all();
+        for (auto &x : th) x.join();
+        th.clear();
+    }
+};
+
+// CAMMIQ_PIPE_TRACE=<file>: timeline of one host-fed query from the library's own HIP events (timing enabled) and host
+// clock -- what rocprofv3 cannot give here: under its tracer the kernels of different streams no longer overlap and the
+// bracket grows from 26 to 32 ms.  Every mark is (name, chunk, stream event | host time); the file lists them relative
+// to the first device event.  Diagnostic: a traced query creates its events on the fly and is a little slower.
+struct PipeTrace {
+    struct Mark { std::string name; int chunk; hipEvent_t ev; double host_ms; };
+    std::vector<Mark> marks;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    const char *file = getenv("CAMMIQ_PIPE_TRACE");
+    bool on() const { return file && file[0]; }
+    void dev(const char *name, int chunk, hipStream_t st)
+    {
+        if (!on()) return;
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) != hipSuccess || hipEventRecord(e, st) != hipSuccess) { (void)hipGetLastError(); return; }
+        marks.push_back(Mark{name, chunk, e, 0.0});
+    }
+    void host(const char *name, int chunk)
+    {
+        if (!on()) return;
+        marks.push_back(Mark{name, chunk, nullptr, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count()});
+    }
+    void dump()
+    {
+        if (!on() || marks.empty()) return;
+        FILE *f = fopen(file, "w");
+        hipEvent_t first = nullptr;
+        for (auto &m : marks) if (m.ev) { first = m.ev; break; }
+        for (auto &m : marks) {
+            if (m.ev) {
+                float ms = 0.f;
+                if (hipEventSynchronize(m.ev) == hipSuccess && first && hipEventElapsedTime(&ms, first, m.ev) == hipSuccess) { if (f) fprintf(f, "dev  %-14s %3d %10.3f\n", m.name.c_str(), m.chunk, ms); }
+                else (void)hipGetLastError();
+                (void)hipEventDestroy(m.ev);
+            } else if (f) fprintf(f, "host %-14s %3d %10.3f\n", m.name.c_str(), m.chunk, m.host_ms);
+        }
+        if (f) fclose(f);
+        marks.clear();
+    }
+};
+
+unsigned widen_threads()
+{
+    if (const char *v = getenv("CAMMIQ_WIDEN_THREADS")) return (unsigned)std::min(64, std::max(1, atoi(v)));
+    const unsigned hc = std::thread::hardware_concurrency();
+    return std::max(1u, std::min(16u, hc / 2));
+}
 
 // What decode + layout leave on the host.  One copy serves every handle of a cq_multi (the
 // index is replicated in HBM, not in host memory).
@@ -101,13 +245,22 @@ struct cq_index {
         uint8_t *d_tight = nullptr;                          // tight rows as they arrive (cq_query_packed_tight), widened into d_packed
         size_t cap_words_h = 0, cap_reads_h = 0, cap_words_d = 0, cap_reads_d = 0, cap_tight = 0;
         hipEvent_t copied = nullptr, copied_lens = nullptr, widened = nullptr, done = nullptr;
-    } slot[3];   // three: the host may enqueue the copy of chunk c+1 while kernel c-1 is still running
+    } slot[kSlots];   // the host may enqueue the copies of the next chunks while the kernels of the chunks before are still running
     hipStream_t s_copy = nullptr, s_copy2 = nullptr, s_comp = nullptr;   // rows | lengths (their own DMA queue) | kernels
     hipStream_t s_widen = nullptr;   // tight rows -> word rows, beside the classify kernel of the chunk before (it leaves wave slots free)
     uint64_t *d_ctr = nullptr; size_t ctr_cap = 0;
     uint32_t *d_rc = nullptr; size_t rc_cap = 0;
     void *h_bounce[2] = {nullptr, nullptr};
     hipEvent_t ev_bounce[2] = {nullptr, nullptr};
+    // rcount's narrow way back (fetch_rcount_narrow)
+    uint8_t *d_rc8 = nullptr; size_t rc8_cap = 0;
+    uint2 *d_esc = nullptr; uint32_t *d_esc_count = nullptr; uint32_t esc_cap = 0;
+    uint8_t *h_ring = nullptr;                 // kNarrowRing x kNarrowPiece, page-locked
+    uint2 *h_esc = nullptr; uint32_t *h_esc_count = nullptr;
+    hipEvent_t ev_ring[kNarrowRing] = {};
+    hipEvent_t ev_narrow = nullptr;
+    WidenPool *pool = nullptr;
+    PipeTrace *trace = nullptr;                // CAMMIQ_PIPE_TRACE: the query being traced (classify_range .. fetch_counts)
 };
 
 // One RCCL communicator bound to one handle's device.
@@ -172,6 +325,15 @@ void release_device(cq_index *ix)
     if (ix->s_widen) (void)hipStreamDestroy(ix->s_widen);
     if (ix->d_ctr) (void)hipFree(ix->d_ctr);
     if (ix->d_rc) (void)hipFree(ix->d_rc);
+    if (ix->pool) { ix->pool->stop(); delete ix->pool; ix->pool = nullptr; }
+    if (ix->d_rc8) (void)hipFree(ix->d_rc8);
+    if (ix->d_esc) (void)hipFree(ix->d_esc);
+    if (ix->d_esc_count) (void)hipFree(ix->d_esc_count);
+    if (ix->h_ring) (void)hipHostFree(ix->h_ring);
+    if (ix->h_esc) (void)hipHostFree(ix->h_esc);
+    if (ix->h_esc_count) (void)hipHostFree(ix->h_esc_count);
+    for (hipEvent_t e : ix->ev_ring) if (e) (void)hipEventDestroy(e);
+    if (ix->ev_narrow) (void)hipEventDestroy(ix->ev_narrow);
 }
 
 // (Re)allocate the SC-mode pair map with `slots` slots (power of two), empty.
@@ -428,6 +590,7 @@ void drop_host_image(HostIndex &H)
 
 struct LoadTimer;
 void warm_workspace(cq_index *ix, LoadTimer *lt = nullptr);   // below, next to the host-fed pipeline it prepares
+int ensure_narrow(cq_index *ix, uint64_t nl);                 // below, with the narrow rcount fetch
 
 double table_budget(int device)
 {
@@ -596,6 +759,68 @@ int cq_last_launch_info(cq_index *ix, cq_launch_info *out)
     return CQ_OK;
 }
 
+int cq_calibrate(cq_index *ix, cq_calibration *out)
+{
+    if (!ix || !out) return fail(CQ_ERR_ARG, "cq_calibrate: NULL argument");
+    if (ix->device < 0) return fail(CQ_ERR_NO_DEVICE, "index was loaded host-only");
+    memset(out, 0, sizeof *out);
+    const auto t_begin = std::chrono::steady_clock::now();
+    CQ_HIP(hipSetDevice(ix->device));
+    const uint64_t n_units = ix->H->img.n_buckets_alloc * 4;   // 16-byte units of the table
+    if (n_units == 0) return fail(CQ_ERR_ARG, "cq_calibrate: empty table");
+    const cq::FlatImage &img = ix->H->img;
+    const uint64_t n_atom = std::max<uint64_t>(img.n_leaves[0] + img.n_leaves[1], 1u << 20);   // an rcount-sized target
+    const int max_grid = ix->n_cus * 8;
+    uint32_t *d_atom = nullptr, *d_sink = nullptr;
+    uint64_t *d_stamps = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    std::vector<uint64_t> stamps(2 * (size_t)max_grid);
+    int rc = CQ_OK;
+#define CQ_HIPC(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { rc = fail(CQ_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); goto done; } } while (0)
+    {
+        CQ_HIPC(hipMalloc((void **)&d_atom, n_atom * 4));
+        CQ_HIPC(hipMemset(d_atom, 0, n_atom * 4));
+        CQ_HIPC(hipMalloc((void **)&d_sink, 4));
+        CQ_HIPC(hipMalloc((void **)&d_stamps, stamps.size() * 8));
+        CQ_HIPC(hipEventCreate(&e0));
+        CQ_HIPC(hipEventCreate(&e1));
+        for (int mix = 0; mix < 2; mix++) {
+            double best = 0.0, best_clock = 0.0;
+            int best_occ = 0;
+            for (int occ : {4, 6, 8}) {
+                const int grid = ix->n_cus * occ;
+                const int iters = 2048;   // 256 x grid x 2048 loads: ~20 ms at 40 G loads/s
+                CQ_HIPC(cq::launch_calib_gather(mix != 0, (const uint4 *)ix->d_slots, n_units, 64, d_atom, n_atom, d_stamps, d_sink, grid, nullptr));   // warm
+                CQ_HIPC(hipEventRecord(e0, nullptr));
+                CQ_HIPC(cq::launch_calib_gather(mix != 0, (const uint4 *)ix->d_slots, n_units, iters, d_atom, n_atom, d_stamps, d_sink, grid, nullptr));
+                CQ_HIPC(hipEventRecord(e1, nullptr));
+                CQ_HIPC(hipEventSynchronize(e1));
+                float ms = 0.f;
+                CQ_HIPC(hipEventElapsedTime(&ms, e0, e1));
+                CQ_HIPC(hipMemcpy(stamps.data(), d_stamps, (size_t)grid * 16, hipMemcpyDeviceToHost));
+                std::vector<double> mhz;
+                for (int b = 0; b < grid; b++)
+                    if (stamps[2 * b + 1]) mhz.push_back(100.0 * (double)stamps[2 * b] / (double)stamps[2 * b + 1]);
+                std::sort(mhz.begin(), mhz.end());
+                const double rate = (double)grid * 256.0 * iters / (ms * 1e-3) / 1e9;
+                if (rate > best) { best = rate; best_occ = occ; best_clock = mhz.empty() ? 0.0 : mhz[mhz.size() / 2]; }
+            }
+            if (mix) { out->gather16_mix_Glines_s = best; out->clock_MHz_mix = best_clock; out->mix_blocks_per_cu = best_occ; }
+            else { out->gather16_Glines_s = best; out->clock_MHz_gather = best_clock; out->gather_blocks_per_cu = best_occ; }
+        }
+    }
+done:
+#undef CQ_HIPC
+    if (d_atom) (void)hipFree(d_atom);
+    if (d_sink) (void)hipFree(d_sink);
+    if (d_stamps) (void)hipFree(d_stamps);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    out->table_bytes = (double)n_units * 16.0;
+    out->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
+    return rc;
+}
+
 int cq_last_kernel_times(cq_index *ix, float *fast_ms, float *slow_ms)
 {
     if (!ix) return fail(CQ_ERR_ARG, "cq_last_kernel_times: NULL argument");
@@ -746,6 +971,8 @@ void warm_workspace(cq_index *ix, LoadTimer *lt)
     if (nl && !ix->d_rc && hipMalloc((void **)&ix->d_rc, nl * 4) == hipSuccess) ix->rc_cap = nl;
     if (!ix->d_ctr && hipMalloc((void **)&ix->d_ctr, cw * 8) == hipSuccess) ix->ctr_cap = cw;
     if (!ix->d_ovf_list && hipMalloc((void **)&ix->d_ovf_list, kChunk * sizeof(uint32_t)) == hipSuccess) ix->ovf_cap = kChunk;
+    (void)ensure_narrow(ix, nl);
+    lap("  narrow rcount path");
     (void)hipGetLastError();
 }
 
@@ -811,16 +1038,35 @@ int classify_range(cq_index *ix, int mode, const Feed &f, uint64_t lo, uint64_t 
     const bool ascii = f.packed == nullptr && f.tight == nullptr;
     int rc = CQ_OK;
     uint64_t c = 0;
+    PipeTrace *tr = ix->trace;
+    auto tdev = [&](const char *n, uint64_t ch, hipStream_t st) { if (tr) tr->dev(n, (int)ch, st); };
+    auto thost = [&](const char *n, uint64_t ch) { if (tr) tr->host(n, (int)ch); };
+    tdev("query_start", 0, ix->s_comp);
     // inside the loop a failed HIP call ends the loop instead of returning: copies from the caller's memory may be in flight
 #define CQ_HIPB(call) if (hipError_t e_ = (call)) { rc = fail(CQ_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); break; } else (void)0
     // Chunk schedule: equal chunks.  (Ramping the ends -- 1/4 and 1/2 chunks first and last, so that the first copy
     // and the last kernel expose less -- was measured on configs[2]: 31.26 / 31.22 ms against 31.55 / 31.12 ms without,
     // A/B/A/B on one box: the copy queue is the critical path, the last kernel's 0.9 ms is all a ramp can shorten.)
+    // Round 4: the copies are the critical path (25 B per read at the link's ~55 GB/s against ~0.45 ms of kernel per M
+    // reads), so what a schedule can take off the bracket is its END: the last chunk's kernel runs after the last copy
+    // with nothing beside it.  The tail is cut finer (kTail: 1/2, 1/4, 1/4 of a chunk by default; CAMMIQ_CHUNK_TAIL=0 for
+    // equal chunks), the head stays whole.
     std::vector<uint64_t> sched;
-    for (uint64_t left = hi - lo; left > 0;) { const uint64_t n = std::min(kChunk, left); sched.push_back(n); left -= n; }
+    {
+        const int tail_on = getenv("CAMMIQ_CHUNK_TAIL") ? atoi(getenv("CAMMIQ_CHUNK_TAIL")) : 1;
+        const uint64_t chunk = chunk_reads();
+        uint64_t left = hi - lo;
+        std::vector<uint64_t> tail;
+        if (tail_on && left >= 3 * chunk && !ascii) {
+            tail = {chunk / 2, chunk / 4, chunk - chunk / 2 - chunk / 4};
+            left -= chunk;
+        }
+        while (left > 0) { const uint64_t n = std::min(chunk, left); sched.push_back(n); left -= n; }
+        sched.insert(sched.end(), tail.begin(), tail.end());
+    }
     uint64_t c0 = lo;
     for (size_t ci = 0; ci < sched.size() && rc == CQ_OK; c0 += sched[ci], ci++, c++) {
-        cq_index::Slot &sl = ix->slot[c % 3];
+        cq_index::Slot &sl = ix->slot[c % kSlots];
         const uint64_t n = sched[ci];
         uint64_t max_len = f.max_len;
         uint32_t sw = f.sw;
@@ -842,7 +1088,9 @@ int classify_range(cq_index *ix, int mode, const Feed &f, uint64_t lo, uint64_t 
             max_len = *std::max_element(part, part + nt);
             sw = cq_pack_stride_words((uint32_t)max_len);
         }
+        thost("slot_wait", c);
         if (sl.done) { CQ_HIPB(hipEventSynchronize(sl.done)); }   // the kernel that last used this slot
+        thost("slot_free", c);
         rc = slot_reserve(sl, n, sw, ascii);
         if (rc != CQ_OK) break;
         const uint32_t *src_rows = nullptr;
@@ -868,38 +1116,55 @@ int classify_range(cq_index *ix, int mode, const Feed &f, uint64_t lo, uint64_t 
                 CQ_HIPB(hipMalloc((void **)&sl.d_tight, (size_t)n * f.sb));
                 sl.cap_tight = (size_t)n * f.sb;
             }
+            tdev("h2d_begin", c, ix->s_copy);
             CQ_HIPB(hipMemcpyAsync(sl.d_tight, src_tight, (size_t)n * f.sb, hipMemcpyHostToDevice, ix->s_copy));
-        } else
+        } else {
+            tdev("h2d_begin", c, ix->s_copy);
             CQ_HIPB(hipMemcpyAsync(sl.d_packed, src_rows, (size_t)n * sw * 4, hipMemcpyHostToDevice, ix->s_copy));
+        }
         CQ_HIPB(hipEventRecord(sl.copied, ix->s_copy));
-        // the small copy of the lengths goes down its own queue: behind the rows it would put a bubble between
-        // every two large transfers
-        CQ_HIPB(hipMemcpyAsync(sl.d_lens, src_lens, n, hipMemcpyHostToDevice, ix->s_copy2));
-        CQ_HIPB(hipEventRecord(sl.copied_lens, ix->s_copy2));
+        tdev("h2d_end", c, ix->s_copy);
+        // The lengths.  The lane grid is sized by the longest read: take it from the lengths themselves (a max_len that
+        // is too small would silently drop windows) and refuse lengths the rows cannot hold.  The scan runs while the
+        // row copy is in flight -- in front of it the scan delayed every transfer (measured: 1 540 -> 1 325 Mreads/s).
+        // A chunk whose reads all have ONE length (what a sequencing run delivers) does not send its lengths at all:
+        // the device array is filled on the device (2 MB less per 50 MB chunk on the link that bounds the bracket).
+        bool lens_uniform = false;
+        uint32_t longest = 0;
         if (!ascii) {
-            // The lane grid is sized by the longest read: take it from the lengths themselves (a max_len that is too
-            // small would silently drop windows) and refuse lengths the rows cannot hold.  Done while the copies are in
-            // flight -- in front of them the scan delayed every transfer (measured: 1 540 -> 1 325 Mreads/s).
-            uint32_t longest = 0;
-            for (uint64_t r = 0; r < n; r++) longest = std::max<uint32_t>(longest, src_lens[r]);
+            uint32_t shortest = 255;
+            for (uint64_t r = 0; r < n; r++) { const uint32_t l = src_lens[r]; longest = std::max(longest, l); shortest = std::min(shortest, l); }
             if (longest > (f.tight ? f.sb * 4u : sw * 16u)) { rc = fail(CQ_ERR_ARG, "cq_query_packed: a length exceeds what a row of this stride holds"); break; }
             max_len = std::max<uint64_t>(max_len, longest);
+            const bool fill_off = getenv("CAMMIQ_LENS_FILL") && atoi(getenv("CAMMIQ_LENS_FILL")) == 0;   // A/B knob
+            lens_uniform = shortest == longest && !fill_off;
         }
+        // the small copy of the lengths goes down its own queue: behind the rows it would put a bubble between
+        // every two large transfers
+        if (lens_uniform) CQ_HIPB(hipMemsetAsync(sl.d_lens, (int)longest, n, ix->s_copy2));
+        else CQ_HIPB(hipMemcpyAsync(sl.d_lens, src_lens, n, hipMemcpyHostToDevice, ix->s_copy2));
+        CQ_HIPB(hipEventRecord(sl.copied_lens, ix->s_copy2));
         if (f.tight) {   // widen on a queue of its own: in front of the classify kernel it would cost the chunk ~0.1 ms
             CQ_HIPB(hipStreamWaitEvent(ix->s_widen, sl.copied, 0));
+            tdev("widen_begin", c, ix->s_widen);
             CQ_HIPB(cq::launch_widen_rows(sl.d_tight, f.sb, sl.d_packed, sw, n, ix->s_widen));
             CQ_HIPB(hipEventRecord(sl.widened, ix->s_widen));
+            tdev("widen_end", c, ix->s_widen);
             CQ_HIPB(hipStreamWaitEvent(ix->s_comp, sl.widened, 0));
         } else
             CQ_HIPB(hipStreamWaitEvent(ix->s_comp, sl.copied, 0));
         CQ_HIPB(hipStreamWaitEvent(ix->s_comp, sl.copied_lens, 0));
+        tdev("kernel_begin", c, ix->s_comp);
         rc = cq_query_device(ix, mode, sl.d_packed, sl.d_lens, n, sw, (uint32_t)max_len, n_genomes, ix->d_ctr, d_rc,
                              ix->s_comp);
         if (rc != CQ_OK) break;
         CQ_HIPB(hipEventRecord(sl.done, ix->s_comp));
+        tdev("kernel_end", c, ix->s_comp);
+        thost("enqueued", c);
     }
 #undef CQ_HIPB
     if (hipStreamSynchronize(ix->s_comp) != hipSuccess && rc == CQ_OK) rc = fail(CQ_ERR_HIP, "classify kernel failed");
+    thost("kernels_done", c);
     if (rc != CQ_OK) {   // an error may have left copies from the caller's memory in flight with no kernel behind them
         (void)hipStreamSynchronize(ix->s_copy);
         (void)hipStreamSynchronize(ix->s_copy2);
@@ -949,6 +1214,119 @@ int copy_out(cq_index *ix, void *dst, const void *d_src, size_t bytes)
     return CQ_OK;
 }
 
+// Device buffers, page-locked ring, events and worker threads of rcount's narrow way back, for nl leaves.
+// CQ_OK with ix->pool == nullptr afterwards means "not available": the caller takes the plain copy.
+int ensure_narrow(cq_index *ix, uint64_t nl)
+{
+    const bool off = getenv("CAMMIQ_RCOUNT_NARROW") && atoi(getenv("CAMMIQ_RCOUNT_NARROW")) == 0;   // A/B knob
+    const uint64_t from = getenv("CAMMIQ_NARROW_FROM") ? strtoull(getenv("CAMMIQ_NARROW_FROM"), nullptr, 10) : kNarrowFrom;   // test knob
+    if (off || nl < from || nl == 0) {   // not this way (any more): the caller sees no pool and takes the plain copy
+        if (ix->pool) { ix->pool->stop(); delete ix->pool; ix->pool = nullptr; }
+        return CQ_OK;
+    }
+    if (ix->rc8_cap < nl) {
+        if (ix->d_rc8) (void)hipFree(ix->d_rc8);
+        ix->d_rc8 = nullptr; ix->rc8_cap = 0;
+        CQ_HIP(hipMalloc((void **)&ix->d_rc8, (nl + 15) / 16 * 16));
+        ix->rc8_cap = nl;
+    }
+    if (!ix->d_esc) {
+        uint32_t cap = 1u << 20;                                       // 8 MB of (leaf, count) pairs
+        if (const char *v = getenv("CAMMIQ_ESC_CAP")) cap = (uint32_t)std::max(1, atoi(v));   // test knob: force the fall-back
+        CQ_HIP(hipMalloc((void **)&ix->d_esc, (size_t)cap * sizeof(uint2)));
+        CQ_HIP(hipMalloc((void **)&ix->d_esc_count, sizeof(uint32_t)));
+        CQ_HIP(hipHostMalloc((void **)&ix->h_esc, (size_t)cap * sizeof(uint2), hipHostMallocDefault));
+        CQ_HIP(hipHostMalloc((void **)&ix->h_esc_count, sizeof(uint32_t), hipHostMallocDefault));
+        ix->esc_cap = cap;
+    }
+    if (!ix->h_ring) CQ_HIP(hipHostMalloc((void **)&ix->h_ring, (size_t)kNarrowRing * kNarrowPiece, hipHostMallocDefault));
+    for (auto &e : ix->ev_ring) if (!e) CQ_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    if (!ix->ev_narrow) CQ_HIP(hipEventCreateWithFlags(&ix->ev_narrow, hipEventDisableTiming));
+    if (ix->pool && ix->pool->th.size() != widen_threads()) { ix->pool->stop(); delete ix->pool; ix->pool = nullptr; }   // knob changed
+    if (!ix->pool) {
+        WidenPool *p = new (std::nothrow) WidenPool();
+        if (!p) return fail(CQ_ERR_NOMEM, "out of memory");
+        try { p->start(widen_threads()); } catch (...) { p->stop(); delete p; return CQ_OK; }   // no threads to be had: plain copy
+        ix->pool = p;
+    }
+    return CQ_OK;
+}
+
+// rcount (ix->d_rc, nl = n_u + n_d leaves) -> the caller's two uint32 arrays, narrow over the link:
+//   device   narrow_rcount_kernel: uint32 -> one byte per leaf (saturated at 255) + escape list        (~0.1 ms / 84 M leaves)
+//   link     the bytes in kNarrowPiece pieces into a page-locked ring                                   (a quarter of the bytes)
+//   host     the pool's threads widen piece k into rcount_u / rcount_d while piece k+1.. arrive; the
+//            escaped entries are written last.
+// Bit-exact with the plain copy (tests: a leaf forced past 255, the escape list overrun -> *fell_back = true and nothing
+// written).  What a query hands the ILP is unchanged: uint32 per leaf in decode order (query.cpp:1161,1176-1177).
+int fetch_rcount_narrow(cq_index *ix, uint64_t n_u, uint64_t n_d, uint32_t *dst_u, uint32_t *dst_d, bool *fell_back)
+{
+    const uint64_t nl = n_u + n_d;
+    *fell_back = true;
+    int rc = ensure_narrow(ix, nl);
+    if (rc != CQ_OK) return rc;
+    if (!ix->pool) return CQ_OK;
+    WidenPool &P = *ix->pool;
+    const unsigned W = (unsigned)P.th.size();
+    PipeTrace *tr = ix->trace;
+    CQ_HIP(hipMemsetAsync(ix->d_esc_count, 0, sizeof(uint32_t), ix->s_comp));
+    if (tr) tr->dev("narrow_begin", 0, ix->s_comp);
+    CQ_HIP(cq::launch_narrow_rcount(ix->d_rc, nl, ix->d_rc8, ix->d_esc, ix->d_esc_count, ix->esc_cap, ix->s_comp));
+    CQ_HIP(hipEventRecord(ix->ev_narrow, ix->s_comp));
+    if (tr) tr->dev("narrow_end", 0, ix->s_comp);
+    CQ_HIP(hipStreamWaitEvent(ix->s_copy, ix->ev_narrow, 0));
+    // the count of escapes rides on the second copy queue (it must follow the narrow kernel too)
+    hipStream_t s_small = ix->s_copy2 ? ix->s_copy2 : ix->s_copy;
+    if (ix->s_copy2) CQ_HIP(hipStreamWaitEvent(ix->s_copy2, ix->ev_narrow, 0));
+    CQ_HIP(hipMemcpyAsync(ix->h_esc_count, ix->d_esc_count, sizeof(uint32_t), hipMemcpyDeviceToHost, s_small));
+    uint64_t piece = kNarrowPiece;
+    if (const char *v = getenv("CAMMIQ_NARROW_PIECE"))   // test knob: small pieces take a small rcount through the whole ring
+        piece = std::min<uint64_t>(kNarrowPiece, std::max<uint64_t>(64, strtoull(v, nullptr, 10) & ~63ull));
+    const uint64_t np = (nl + piece - 1) / piece;
+    auto piece_bytes = [&](uint64_t k) { return (size_t)std::min<uint64_t>(piece, nl - k * piece); };
+    auto enqueue = [&](uint64_t k) -> hipError_t {
+        hipError_t e = hipMemcpyAsync(ix->h_ring + (k % kNarrowRing) * piece, ix->d_rc8 + k * piece, piece_bytes(k),
+                                      hipMemcpyDeviceToHost, ix->s_copy);
+        return e != hipSuccess ? e : hipEventRecord(ix->ev_ring[k % kNarrowRing], ix->s_copy);
+    };
+    for (uint64_t k = 0; k < np && k < (uint64_t)kNarrowRing; k++) CQ_HIP(enqueue(k));
+    {   // wake the workers: they spin on `ready` from here on
+        std::lock_guard<std::mutex> lk(P.mu);
+        P.ring = ix->h_ring; P.n = nl; P.n_u = n_u; P.n_pieces = np; P.piece = piece; P.dst_u = dst_u; P.dst_d = dst_d;
+        P.ready.store(0); P.workers_done.store(0);
+        for (auto &f : P.fin) f.store(0);
+        P.job_seq++;
+    }
+    P.cv.notify_all();
+    hipError_t bad = hipSuccess;
+    for (uint64_t k = 0; k < np; k++) {
+        if (bad == hipSuccess) bad = hipEventSynchronize(ix->ev_ring[k % kNarrowRing]);
+        P.ready.store(k + 1, std::memory_order_release);                // (after a failed copy the workers widen garbage; the error is returned below)
+        if (k + kNarrowRing < np) {
+            // slot k % ring is free again once every worker is through with piece k
+            const uint64_t want = (uint64_t)W * (k / kNarrowRing + 1);
+            while (P.fin[k % kNarrowRing].load(std::memory_order_acquire) < want) _mm_pause();
+            if (bad == hipSuccess) bad = enqueue(k + kNarrowRing);
+        }
+    }
+    if (tr) { tr->dev("d2h_last_piece", (int)np, ix->s_copy); tr->host("pieces_copied", (int)np); }
+    while (P.workers_done.load(std::memory_order_acquire) < W) _mm_pause();
+    if (tr) tr->host("widened", (int)np);
+    if (bad != hipSuccess) return fail(CQ_ERR_HIP, std::string("narrow rcount copy: ") + hipGetErrorString(bad));
+    CQ_HIP(hipStreamSynchronize(s_small));
+    const uint32_t n_esc = *ix->h_esc_count;
+    if (n_esc > ix->esc_cap) return CQ_OK;                               // more saturated leaves than the list holds: plain copy (fell_back stays true)
+    if (n_esc) {
+        CQ_HIP(hipMemcpy(ix->h_esc, ix->d_esc, (size_t)n_esc * sizeof(uint2), hipMemcpyDeviceToHost));
+        for (uint32_t i = 0; i < n_esc; i++) {
+            const uint64_t leaf = ix->h_esc[i].x;
+            if (leaf < n_u) dst_u[leaf] = ix->h_esc[i].y; else dst_d[leaf - n_u] = ix->h_esc[i].y;
+        }
+    }
+    *fell_back = false;
+    return CQ_OK;
+}
+
 // Counter block + rcount of ix (device) -> the caller's cq_counts.  Pair counts are NOT handled here.
 int fetch_counts(cq_index *ix, int mode, uint32_t n_genomes, cq_counts *out, uint64_t *flags)
 {
@@ -958,9 +1336,14 @@ int fetch_counts(cq_index *ix, int mode, uint32_t n_genomes, cq_counts *out, uin
     std::vector<uint64_t> ctr(cw, 0);
     CQ_HIP(hipMemcpy(ctr.data(), ix->d_ctr, cw * 8, hipMemcpyDeviceToHost));
     if (mode == CQ_MODE_P && ix->d_rc) {
-        int rc = copy_out(ix, out->rcount_u, ix->d_rc, img.n_leaves[0] * 4);
-        if (rc == CQ_OK) rc = copy_out(ix, out->rcount_d, ix->d_rc + img.n_leaves[0], img.n_leaves[1] * 4);
+        bool plain = true;
+        int rc = fetch_rcount_narrow(ix, img.n_leaves[0], img.n_leaves[1], out->rcount_u, out->rcount_d, &plain);
         if (rc != CQ_OK) return rc;
+        if (plain) {
+            rc = copy_out(ix, out->rcount_u, ix->d_rc, img.n_leaves[0] * 4);
+            if (rc == CQ_OK) rc = copy_out(ix, out->rcount_d, ix->d_rc + img.n_leaves[0], img.n_leaves[1] * 4);
+            if (rc != CQ_OK) return rc;
+        }
     }
     memcpy(out->cnt_u, ctr.data(), G1 * 8);
     memcpy(out->cnt_d, ctr.data() + G1, G1 * 8);
@@ -984,10 +1367,12 @@ int query_one(cq_index *ix, int mode, const Feed &f, uint64_t n_reads, uint32_t 
             CQ_HIP(hipSetDevice(ix->device));
             if ((rc = pairs_clear(ix)) != CQ_OK) return rc;
         }
+        PipeTrace trace;
+        ix->trace = trace.on() ? &trace : nullptr;
         rc = classify_range(ix, mode, f, 0, n_reads, n_genomes);
-        if (rc != CQ_OK) return rc;
         uint64_t flags = 0;
-        rc = fetch_counts(ix, mode, n_genomes, out, &flags);
+        if (rc == CQ_OK) rc = fetch_counts(ix, mode, n_genomes, out, &flags);
+        if (ix->trace) { trace.host("query_done", 0); trace.dump(); ix->trace = nullptr; }
         if (rc != CQ_OK) return rc;
         if (mode != CQ_MODE_SC) return CQ_OK;
         if (flags != 0) {

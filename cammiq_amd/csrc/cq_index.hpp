@@ -108,6 +108,14 @@ void make_empty_table(uint32_t hash_len, DecodedTable &out);
 int build_image(const DecodedTable &u, const DecodedTable &d, double keys_per_bucket, uint32_t minimizer_len,
                 FlatImage &img, std::string &err);
 
+// The two stages of build_image.  prepare_image: everything but the table (linked + path-compressed trie, leaf refIDs,
+// hash range, minimizer length) and vals[i] = final trie code of entry i in its own table -- entries [0, nb_u) are
+// ht_u's buckets in file order, the rest ht_d's.  finish_image_host lays the table out on the host from
+// (bucket_key, vals); cq_layout_gpu.hip does the same on the device, byte for byte.
+int prepare_image(const DecodedTable &u, const DecodedTable &d, double keys_per_bucket, uint32_t minimizer_len,
+                  FlatImage &img, RawVec<uint32_t> &vals, std::string &err);
+int finish_image_host(const DecodedTable &u, const DecodedTable &d, const RawVec<uint32_t> &vals, FlatImage &img, std::string &err);
+
 // Optional on-disk cache of the finished image (cq_cache.cpp).
 struct SourceStamp { uint64_t size[4]; int64_t mtime_ns[4]; };   // index_u, .aux, index_d, .aux (0 = absent)
 bool stamp_sources(const std::string &path_u, const std::string &path_d, SourceStamp &s);

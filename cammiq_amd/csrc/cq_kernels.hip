@@ -891,6 +891,103 @@ hipError_t launch_widen_rows(const uint8_t *tight, uint32_t sb, uint32_t *rows, 
     return hipGetLastError();
 }
 
+// rcount leaves the device NARROW: one byte per leaf (the count, saturated at 255) plus an escape list of
+// (leaf, count) for the few entries of 255 and more; the host widens into the caller's uint32 arrays
+// (pleafNode::rcount is a uint32, hashtrie.hpp:43) and overwrites the escaped entries -- bit-exact, a quarter of
+// the bytes on the link behind the last classify kernel.  A thread takes 16 consecutive entries: four 16-byte
+// loads, one 16-byte store.  *esc_count may end above esc_cap: the host then falls back to the plain uint32 copy.
+__global__ void __launch_bounds__(256) narrow_rcount_kernel(const uint32_t *__restrict__ rc, uint64_t n, uint8_t *__restrict__ out8,
+                                                            uint2 *__restrict__ esc, uint32_t *__restrict__ esc_count, uint32_t esc_cap)
+{
+    const uint64_t n16 = n / 16, stride = (uint64_t)gridDim.x * blockDim.x, tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    auto squeeze = [&](uint32_t v, uint64_t idx) -> uint32_t {
+        if (v < 255u) return v;
+        const uint32_t at = atomicAdd(esc_count, 1u);
+        if (at < esc_cap) esc[at] = make_uint2((uint32_t)idx, v);
+        return 255u;
+    };
+    for (uint64_t g = tid; g < n16; g += stride) {
+        const uint4 *src = (const uint4 *)(rc + g * 16);
+        uint32_t w[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const uint4 v = src[q];
+            const uint64_t i0 = g * 16 + (uint64_t)q * 4;
+            w[q] = squeeze(v.x, i0) | squeeze(v.y, i0 + 1) << 8 | squeeze(v.z, i0 + 2) << 16 | squeeze(v.w, i0 + 3) << 24;
+        }
+        ((uint4 *)out8)[g] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    for (uint64_t i = n16 * 16 + tid; i < n; i += stride) out8[i] = (uint8_t)squeeze(rc[i], i);
+}
+
+hipError_t launch_narrow_rcount(const uint32_t *rc, uint64_t n, uint8_t *out8, uint2 *esc, uint32_t *esc_count, uint32_t esc_cap,
+                                hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    uint64_t grid = (n / 16 + 255) / 256;
+    if (grid < 1) grid = 1;
+    if (grid > 256 * 16) grid = 256 * 16;
+    hipLaunchKernelGGL(narrow_rcount_kernel, dim3((unsigned)grid), dim3(256), 0, stream, rc, n, out8, esc, esc_count, esc_cap);
+    return hipGetLastError();
+}
+
+// ---- board calibrators (cq_calibrate; diagnostic, never on the classify path) ------------------------------------
+// What the classify kernel is held against -- the chip's rate of random 16-byte loads from a table of THIS size -- and
+// the shader clock the chip holds under such a load, measured on the board a run is on, in about a second.  The
+// product kernel stays stamp-free; these kernels carry the s_memtime / s_memrealtime stamps.
+//   MIX = false: every lane issues `iters` independent random 16-byte loads from the handle's own table (the probe
+//                loop's access: one key_lo quad per minimizer run), four in flight per lane.
+//   MIX = true:  the same loads with what the real kernel has beside them and a plain gather lacks: a returnless
+//                global atomic to a random word of an rcount-sized array per 16 loads (rcount++), and LDS traffic
+//                (per load: a 16-byte store of the loaded quad into a wave-private region and two 8-byte reads back).
+// stamps[2 b], stamps[2 b + 1] = shader cycles / 100 MHz ticks workgroup b's first wave spent in the loop.
+template <bool MIX>
+__global__ void __launch_bounds__(256) calib_gather_kernel(const uint4 *__restrict__ tab, uint64_t n_units, int iters,
+                                                           uint32_t *__restrict__ atom, uint64_t n_atom, uint64_t *__restrict__ stamps,
+                                                           uint32_t *__restrict__ sink)
+{
+    __shared__ uint4 lds[MIX ? 256 * 4 : 1];
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t s = (uint64_t)gid * 0x9E3779B97F4A7C15ull + 12345;
+    uint32_t acc = 0;
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int i = 0; i < iters; i += 4) {
+        uint64_t idx[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            s = s * 6364136223846793005ull + 1442695040888963407ull;
+            idx[u] = (uint64_t)(((__uint128_t)s * n_units) >> 64);
+        }
+        uint4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) v[u] = tab[idx[u]];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            acc += v[u].x ^ v[u].w;
+            if (MIX) {
+                lds[threadIdx.x * 4 + u] = v[u];
+                const uint2 *back = (const uint2 *)&lds[(threadIdx.x ^ 1u) * 4 + u];   // the neighbour lane's quad: a real LDS round trip
+                acc += back[0].x + back[1].y;
+            }
+        }
+        if (MIX && (i & 12) == 0) {   // one returnless atomic per 16 loads
+            s = s * 6364136223846793005ull + 1442695040888963407ull;
+            atomicAdd(atom + (uint64_t)(((__uint128_t)s * n_atom) >> 64), 0u);   // adds nothing: the array keeps its contents
+        }
+    }
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0) { stamps[2 * blockIdx.x] = c1 - c0; stamps[2 * blockIdx.x + 1] = r1 - r0; }
+    if (acc == 0x12345678u) sink[0] = acc;
+}
+
+hipError_t launch_calib_gather(bool mix, const uint4 *tab, uint64_t n_units, int iters, uint32_t *atom, uint64_t n_atom,
+                               uint64_t *stamps, uint32_t *sink, int grid, hipStream_t stream)
+{
+    if (mix) hipLaunchKernelGGL(calib_gather_kernel<true>, dim3((unsigned)grid), dim3(256), 0, stream, tab, n_units, iters, atom, n_atom, stamps, sink);
+    else hipLaunchKernelGGL(calib_gather_kernel<false>, dim3((unsigned)grid), dim3(256), 0, stream, tab, n_units, iters, atom, n_atom, stamps, sink);
+    return hipGetLastError();
+}
+
 hipError_t launch_accumulate(uint64_t *dst64, const uint64_t *src64, uint64_t n64, uint32_t *dst32,
                              const uint32_t *src32, uint64_t n32, hipStream_t stream)
 {

@@ -233,8 +233,12 @@ struct StageTimer {   // CAMMIQ_LOAD_TIMING=1: stage timings on stderr (diagnost
 };
 }  // namespace
 
-int build_image(const DecodedTable &u, const DecodedTable &d, double keys_per_bucket, uint32_t minimizer_len,
-                FlatImage &img, std::string &err)
+// Stage 1 of the layout, always on the host: link the two tries, give leaves global ids, path-compress, and produce
+// every bucket's final trie code.  vals[i] is entry i's code in ITS table (entries [0, nb_u) are ht_u's buckets in file
+// order, [nb_u, nb_u + nb_d) ht_d's); the table itself is laid out from (bucket_key, vals) either by finish_image_host
+// below or on the device (cq_layout_gpu.hip) -- byte-identical results.
+int prepare_image(const DecodedTable &u, const DecodedTable &d, double keys_per_bucket, uint32_t minimizer_len,
+                  FlatImage &img, RawVec<uint32_t> &vals, std::string &err)
 {
     StageTimer st;
     img = FlatImage();
@@ -304,9 +308,9 @@ int build_image(const DecodedTable &u, const DecodedTable &d, double keys_per_bu
     img.n_buckets = nbk;
     const uint32_t n_buckets = (uint32_t)nbk;
 
-    std::unique_ptr<Entry[]> ent(new Entry[nb_u + nb_d ? nb_u + nb_d : 1]);   // uninitialised: filled (first touched) in parallel
-    advise_huge(ent.get(), (nb_u + nb_d) * sizeof(Entry));
     const size_t n_ent = nb_u + nb_d;
+    vals.resize(n_ent ? n_ent : 1);
+    advise_huge(vals.data(), n_ent * sizeof(uint32_t));
     // trie codes first: a bucket root that is a leaf (the usual case) is its own code; the others go
     // through path compression, which appends to one node array and therefore runs serially, in file order
     {
@@ -314,9 +318,8 @@ int build_image(const DecodedTable &u, const DecodedTable &d, double keys_per_bu
         std::vector<std::vector<uint64_t>> deep(nte);
         parallel_for(nte, [&](unsigned t) {
             for (uint64_t i = (nb_u + nb_d) * t / nte, e = (nb_u + nb_d) * (t + 1) / nte; i < e; i++) {
-                if (i < nb_u) ent[i] = Entry{0, (uint32_t)i, u.bucket_key[i], u.bucket_code[i], 0};
-                else ent[i] = Entry{0, (uint32_t)(i - nb_u), d.bucket_key[i - nb_u], 0, relink_d(d.bucket_code[i - nb_u])};
-                const uint32_t code = ent[i].val_u | ent[i].val_d;
+                const uint32_t code = i < nb_u ? u.bucket_code[i] : relink_d(d.bucket_code[i - nb_u]);
+                vals[i] = code;
                 if (code && !(code & CQ_LEAF_BIT)) deep[t].push_back(i);
             }
         });
@@ -327,10 +330,7 @@ int build_image(const DecodedTable &u, const DecodedTable &d, double keys_per_bu
         parallel_for(nte, [&](unsigned t) {
             local[t].push_back(Node{{0, 0, 0, 0}});
             Compressor comp{linked, local[t], img.leaf_r1.data(), img.leaf_r2.data()};
-            for (uint64_t i : deep[t]) {
-                if (i < nb_u) ent[i].val_u = comp.run(ent[i].val_u);
-                else ent[i].val_d = comp.run(ent[i].val_d);
-            }
+            for (uint64_t i : deep[t]) vals[i] = comp.run(vals[i]);
         });
         std::vector<uint64_t> base(nte + 1, 1);   // global index of worker t's local node 1
         for (unsigned t = 0; t < nte; t++) base[t + 1] = base[t] + (local[t].size() - 1);
@@ -345,25 +345,40 @@ int build_image(const DecodedTable &u, const DecodedTable &d, double keys_per_bu
                 else for (int c = 0; c < 4; c++) n.child[c] = reloc(n.child[c]);
                 img.nodes[base[t] - 1 + k] = n;
             }
-            for (uint64_t i : deep[t]) {
-                if (i < nb_u) ent[i].val_u = reloc(ent[i].val_u);
-                else ent[i].val_d = reloc(ent[i].val_d);
-            }
+            for (uint64_t i : deep[t]) vals[i] = reloc(vals[i]);
             std::vector<Node>().swap(local[t]);
         });
     }
     st.lap("compress tries");
-    // ... then the home buckets (a minimizer scan per key: the expensive part) on all cores
+    if (img.nodes.size() >= (1ull << 30)) { err = "more than 2^30 trie nodes after path compression"; return CQ_ERR_LIMIT; }
+    (void)n_buckets;
+    return CQ_OK;
+}
+
+// Stage 2 on the host: home buckets, sort, merge, placement sweep -> img.table (the reference image of the layout;
+// what handles without a device, the image cache and the tests of the device layout use).
+int finish_image_host(const DecodedTable &u, const DecodedTable &d, const RawVec<uint32_t> &vals, FlatImage &img, std::string &err)
+{
+    StageTimer st;
+    const uint64_t nb_u = u.bucket_key.size(), nb_d = d.bucket_key.size();
+    const size_t n_ent = nb_u + nb_d;
+    const uint64_t nbk = img.n_buckets;
+    const uint32_t n_buckets = (uint32_t)nbk;
+    std::unique_ptr<Entry[]> ent(new Entry[n_ent ? n_ent : 1]);   // uninitialised: filled (first touched) in parallel
+    advise_huge(ent.get(), n_ent * sizeof(Entry));
+    // the home buckets (a minimizer scan per key: the expensive part) on all cores
     {
         const unsigned nt = worker_count(n_ent);
         const uint32_t hl = img.hash_len, ml = img.minimizer_len;
         parallel_for(nt, [&](unsigned t) {
             const size_t lo = n_ent * t / nt, hi = n_ent * (t + 1) / nt;
-            for (size_t i = lo; i < hi; i++) ent[i].home = cq_home_bucket(ent[i].key, hl, ml, n_buckets);
+            for (size_t i = lo; i < hi; i++) {
+                const uint64_t key = i < nb_u ? u.bucket_key[i] : d.bucket_key[i - nb_u];
+                ent[i] = i < nb_u ? Entry{0, (uint32_t)i, key, vals[i], 0} : Entry{0, (uint32_t)(i - nb_u), key, 0, vals[i]};
+                ent[i].home = cq_home_bucket(key, hl, ml, n_buckets);
+            }
         });
     }
-    if (img.nodes.size() >= (1ull << 30)) { err = "more than 2^30 trie nodes after path compression"; return CQ_ERR_LIMIT; }
-    std::vector<Node>().swap(linked);
     st.lap("home buckets");
     std::vector<size_t> part_begin;
     const std::unique_ptr<Entry[]> sorted = sort_entries(ent, n_ent, n_buckets, part_begin);
@@ -535,6 +550,15 @@ int build_image(const DecodedTable &u, const DecodedTable &d, double keys_per_bu
     img.n_overflowed = overflowed;
     st.lap("placement sweep");
     return CQ_OK;
+}
+
+int build_image(const DecodedTable &u, const DecodedTable &d, double keys_per_bucket, uint32_t minimizer_len,
+                FlatImage &img, std::string &err)
+{
+    RawVec<uint32_t> vals;
+    int rc = prepare_image(u, d, keys_per_bucket, minimizer_len, img, vals, err);
+    if (rc != CQ_OK) return rc;
+    return finish_image_host(u, d, vals, img, err);
 }
 
 void image_lookup(const FlatImage &img, uint64_t key, uint32_t &val_u, uint32_t &val_d, uint32_t *chain_len)

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define CQ_ABI_VERSION 4   /* 4: cq_last_launch_info; every host-fed SC-mode query starts from an empty pair map */
+#define CQ_ABI_VERSION 5   /* 5: cq_calibrate; 4: cq_last_launch_info; every host-fed SC-mode query starts from an empty pair map */
 
 /*
  * Design limits of one handle (= one GPU's replica of the index).  The reference's pointer trie has none beyond its
@@ -279,6 +279,30 @@ typedef struct cq_launch_info {
     int32_t minimizer_len;    /* m of the index (16 / 18): part of the instantiation's name when fixed_shape */
 } cq_launch_info;
 int cq_last_launch_info(cq_index *idx, cq_launch_info *out);
+
+/*
+ * Diagnostic, no reference analogue: what THIS board gives the classify kernel to work with, measured in about a
+ * second on the handle's own table in HBM (same bytes, same allocation, nothing is modified).  The classify kernel is
+ * bound by the chip's rate of random loads from a multi-GB table, and boards of one pool differ in it by more than
+ * 10 %: a benchmark line that carries these numbers says whether a slow run was the board or the build.
+ *   gather16_Glines_s      random 16-byte loads per second (in 10^9), four independent loads in flight per lane, best of
+ *                          4 / 6 / 8 workgroups per CU -- the ceiling the probe loop's bucket reads are held against
+ *   gather16_mix_Glines_s  the same loads with a returnless global atomic per 16 loads into an rcount-sized array and
+ *                          LDS stores / reads beside them (what the real kernel has and a plain gather lacks)
+ *   clock_MHz_*            shader clock held DURING each of the two kernels: shader cycles / 100 MHz constant-clock
+ *                          ticks (s_memtime / s_memrealtime), median over workgroups
+ * Not part of any query; a handle without a device returns CQ_ERR_NO_DEVICE.
+ */
+typedef struct cq_calibration {
+    double gather16_Glines_s;
+    double gather16_mix_Glines_s;
+    double clock_MHz_gather;
+    double clock_MHz_mix;
+    double table_bytes;         /* bytes of the table the loads were spread over */
+    double seconds;             /* wall time the calibration took */
+    int32_t gather_blocks_per_cu, mix_blocks_per_cu;   /* the occupancy that gave the best rate */
+} cq_calibration;
+int cq_calibrate(cq_index *idx, cq_calibration *out);
 
 /* ---- multi-GPU -----------------------------------------------------------------------------
  * No reference analogue: the reference's one parallel axis is the OpenMP loop over reads

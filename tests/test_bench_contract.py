@@ -40,7 +40,7 @@ def test_single_gpu_line():
     assert cb["value_thread_local"] > 0 and cb["value_atomic"] > 0 and cb["host_cores_online"] >= cb["cores"]
     o = j["outcome"]
     assert o["reads"] == 2 * 200000 and o["nskipped"] == 0
-    assert j["host_fed"]["Mreads_s"] > 0 and j["host_fed"]["bytes_per_read_on_the_wire"] == 26
+    assert j["host_fed"]["Mreads_s"] > 0 and j["host_fed"]["bytes_per_read_on_the_wire"] == 25
     assert j["value_survey_8d_bracket"] == j["host_fed"]["Mreads_s"]
 
 

@@ -137,7 +137,8 @@ def test_configs4_index_at_size():
     """configs[4]'s per-GPU shard with the index at the size this box can build -- 15 000 genomes x 3.45 Mbp at the
     survey's marker density = 1.26e9 markers (81 GB of table, ~97 GB on the device) where the host has the ~170 GB the
     build peaks at, proportionally shorter genomes where it has not (CAMMIQ_CFG4_GENOME_LEN pins a length) -- and
-    20 M x 150 bp reads in ONE launch.  tools/configs4.py does the work: property checks that hold at any size
+    125 M x 150 bp reads (configs[4]'s per-GPU read count) in ONE launch, through the device door and -- the whole shard --
+    through the host-fed door.  tools/configs4.py does the work: property checks that hold at any size
     (conservation, idempotence, halves and the eight cq_shard_range shards add up leaf by leaf, host-fed door ==
     device door) and the oracle on a 100 k-read slice against the generator's sub-index (the full index's markers
     whose h-mer occurs in the slice: tests/test_subindex.py)."""
@@ -153,10 +154,19 @@ def test_configs4_index_at_size():
         L = int(os.environ["CAMMIQ_CFG4_GENOME_LEN"])
     if L < 400_000:
         pytest.skip(f"host memory ({avail / 1e9:.0f} GB available, {shm / 1e9:.0f} GB of /dev/shm) is too small for an index beyond the shape test's")
-    rec = configs4.run(G, L, 20_000_000, 150, log=lambda s: print(s, flush=True))
+    n_reads = int(os.environ.get("CAMMIQ_CFG4_READS", "125000000"))      # configs[4]: 1 B x 150 bp over 8 GPUs = 125 M per GPU
+    rec = configs4.run(G, L, n_reads, 150, log=lambda s: print(s, flush=True))
     out = os.path.join(root, "gpurun_out")
     os.makedirs(out, exist_ok=True)
     json.dump(rec, open(os.path.join(out, "cfg4_test_record.json"), "w"), indent=1)
+    # the size this ran at, where a -q run keeps it: pytest's warnings summary (a pass prints nothing else)
+    import warnings
+    warnings.warn(f"configs[4] ran at {G} genomes x {L} bp = {rec['leaves_u'] + rec['leaves_d']} markers "
+                  f"({rec['table']['table_GB']} GB table, {rec['table']['device_GB']} GB on the device, m = {rec['table']['minimizer_len']}), "
+                  f"{n_reads} x 150 bp in one launch: kernel {rec['kernel_ms']} ms ({rec['kernel_Gwindows_s']} G windows/s), "
+                  f"host-fed door on the whole shard {rec['host_fed_Mreads_s']} Mreads/s, cq_index_load "
+                  f"{rec['stages_s'].get('cq_index_load (decode+layout+upload)')} s, peak host RSS {rec['peak_host_RSS_GB']} GB; "
+                  f"host had {avail / 1e9:.0f} GB available")
     bad = [k for k, v in rec["checks"].items() if v is False]
     assert not bad, f"{bad} failed at {rec['leaves_u']} + {rec['leaves_d']} markers"
     assert rec["checks"]["genomes_hit"] > 14_900

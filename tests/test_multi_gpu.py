@@ -149,6 +149,49 @@ def test_large_rcount_comes_back_through_the_bounce_buffers(tmp_path):
     assert_same(ix.query_packed(packed, lens, 100, G, out=ix.counts_out(G, pinned=True)), ref, "pinned out")
 
 
+@pytest.mark.parametrize("how", ["ring", "escapes_overrun", "off"])
+def test_rcount_comes_back_narrow_and_exact(tmp_path, monkeypatch, how):
+    """rcount crosses the link as one byte per leaf + an escape list for counts of 255 and more and is widened into the
+    caller's uint32 arrays by the library (cq_api.cpp fetch_rcount_narrow): bit-exact with the oracle with leaves forced far
+    past 255 (every read of a block repeated 700 times), through a ring of small pieces (each ring slot reused many
+    times, pieces that straddle the u / d boundary), into pinned and into pageable arrays, for every host-fed door; when
+    the escape list overruns (forced: 3 entries) the plain uint32 copy takes over, silently and exactly."""
+    from cammiq_amd import bigsynth
+    G = 40
+    w = bigsynth.World(seed=11, n_genomes=G, genome_len=400_000, pair_share=0.3)
+    pu, pd = str(tmp_path / "index_u.bin1"), str(tmp_path / "index_d.bin2")
+    nu, nd = w.write_index(pu, pd)
+    b, o = w.reads(seed=4, n=3000, length=100)
+    rb = b.reshape(3000, 100)
+    hot = np.repeat(rb[:40], 700, axis=0)                       # 40 reads x 700: their leaves count 700 and more
+    allb = np.ascontiguousarray(np.concatenate([rb, hot]).ravel())
+    n = 3000 + 40 * 700
+    allo = np.arange(n + 1, dtype=np.uint64) * np.uint64(100)
+    ref = oracle_lib.OracleIndex(pu, pd).query(allb, allo, G, nthreads=8)
+    assert max(int(ref["rcount_u"].max()), int(ref["rcount_d"].max())) >= 700
+    assert int((ref["rcount_u"] >= 255).sum() + (ref["rcount_d"] >= 255).sum()) > 3
+    monkeypatch.setenv("CAMMIQ_NARROW_FROM", "1")
+    if how == "ring":
+        monkeypatch.setenv("CAMMIQ_NARROW_PIECE", "4096")       # (nu + nd) / 4096 pieces through the 8 ring slots
+        assert (nu + nd) // 4096 > 24 and nu % 4096 != 0
+    elif how == "escapes_overrun":
+        monkeypatch.setenv("CAMMIQ_ESC_CAP", "3")
+    else:
+        monkeypatch.setenv("CAMMIQ_RCOUNT_NARROW", "0")
+    ix = cq.Index(pu, pd, device=0)
+    assert_same(ix.query(allb, allo, G), ref, f"{how}: ascii door, pageable out")
+    packed, lens, _ = cq.pack_reads(allb, allo, 26)
+    assert_same(ix.query_packed(packed, lens, 100, G, out=ix.counts_out(G, pinned=True)), ref, f"{how}: packed door, pinned out")
+    tight, tl, _ = cq.pack_reads_tight(allb, allo, 26)
+    out = ix.counts_out(G, pinned=True)
+    out.ru[:] = 0xABABABAB                                      # stale contents must be overwritten, every entry
+    out.rd[:] = 0xABABABAB
+    assert_same(ix.query_packed_tight(tight, tl, 100, G, out=out), ref, f"{how}: tight door, pinned out")
+    assert_same(ix.query_packed_tight(tight, tl, 100, G), ref, f"{how}: tight door again (buffers reused)")
+    m = cq.Multi(pu, pd, [0, 0])
+    assert_same(m.query_packed_tight(tight, tl, 100, G), ref, f"{how}: two shards")
+
+
 def test_pair_map_grows_instead_of_failing(tmp_path, monkeypatch):
     """query64_sc's read_cnts_b with more distinct pairs than the device map has slots: the library
     grows the map and classifies again (it used to return CQ_ERR_LIMIT); output arrays that are too

@@ -1,14 +1,15 @@
 #!/usr/bin/env python3
 """tools/configs4.py -- BASELINE.json configs[4]'s per-GPU shard at the size one box can build: ~15 000 genomes,
 --both index sized to what host memory allows (target 1.26e9 markers = 15 000 x 3.45 Mbp at the survey's marker
-density: ~81 GB of table, ~97 GB on the device), 150-bp reads, >= 20 M per launch.
+density: ~81 GB of table, ~97 GB on the device), 150-bp reads, 125 M per launch (configs[4]'s 1 B reads over 8 GPUs).
 
-    python tools/configs4.py [--genomes 15000] [--genome-len 3450000] [--reads 20000000] [--out gpurun_out/cfg4.json]
+    python tools/configs4.py [--genomes 15000] [--genome-len 3450000] [--reads 125000000] [--out gpurun_out/cfg4.json]
 
 What it checks (run(); tests/test_gpu_configs.py::test_configs4_index_at_size asserts on the record):
   * properties that hold at any size: conservation of reads, idempotence, two unequal halves and the eight
-    cq_shard_range shards add up to the whole counter by counter and leaf by leaf, the packed host-fed door gives
-    the device door's counters;
+    cq_shard_range shards add up to the whole counter by counter and leaf by leaf, the host-fed door (tight rows in
+    page-locked memory, the whole shard in one query; word rows from pageable memory on a part) gives the device
+    door's counters and rcount;
   * the oracle on a 100 k-read slice.  The oracle cannot hold 10^9 markers (~100 B per node), so it loads the
     SUB-INDEX the generator writes beside the full one: exactly the full index's markers whose h-mer occurs in
     the slice (either strand).  For those reads every lookup finds in the sub-index what it finds in the full one
@@ -79,7 +80,7 @@ def size_for_this_box(genomes: int, want_len: int, host_budget_bytes: float | No
     return min(want_len, L), avail, shm
 
 
-def run(genomes=15000, genome_len=3_450_000, n_reads=20_000_000, rl=150, slice_reads=100_000, log=print, workdir=None):
+def run(genomes=15000, genome_len=3_450_000, n_reads=125_000_000, rl=150, slice_reads=100_000, log=print, workdir=None):
     import torch
     import cammiq_amd as cq
     from cammiq_amd import bigsynth
@@ -128,25 +129,37 @@ def run(genomes=15000, genome_len=3_450_000, n_reads=20_000_000, rl=150, slice_r
         for p in (pu, pu + ".aux", pd, pd + ".aux"):
             os.unlink(p)                       # give the page cache back before the reads are generated
 
-        # ---- the batch: n_reads x rl, packed once, resident in HBM
+        # ---- the batch: n_reads x rl, packed once: word rows resident in HBM (the device door), tight rows in page-locked
+        #      host memory (the host-fed door, what crosses the link), the first nh word rows also in pageable memory
         t0 = time.time()
-        sw = cq.stride_words(rl)
-        packed = np.empty((n_reads, sw), np.uint32)
-        lens = np.empty(n_reads, np.uint8)
+        sw, sb = cq.stride_words(rl), cq.stride_bytes(rl)
+        nh = min(n_reads, 6_000_000)
+        packed = np.empty((nh, sw), np.uint32)
+        lens = np.empty(nh, np.uint8)
+        hp = cq.host_array(n_reads * sb, np.uint8).reshape(n_reads, sb)
+        hl = cq.host_array(n_reads, np.uint8)
+        dp = torch.empty((n_reads, sw), dtype=torch.int32, device="cuda")
+        dl = torch.empty(n_reads, dtype=torch.uint8, device="cuda")
         chunk = 5_000_000
         buf = np.empty(min(chunk, n_reads) * rl, np.uint8)
         for c0 in range(0, n_reads, chunk):
             m = min(chunk, n_reads - c0)
             w.reads_into(buf, 1000, c0, m, rl)
-            pk, ln, sk = cq.pack_reads(buf[:m * rl], np.arange(m + 1, dtype=np.uint64) * np.uint64(rl), h, sw)
+            offs = np.arange(m + 1, dtype=np.uint64) * np.uint64(rl)
+            pk, ln, sk = cq.pack_reads(buf[:m * rl], offs, h, sw)
             assert sk == 0
-            packed[c0:c0 + m] = pk
-            lens[c0:c0 + m] = ln
+            _, _, tsk = cq.pack_reads_tight(buf[:m * rl], offs, h, sb, out=(hp[c0:c0 + m], hl[c0:c0 + m]))
+            assert tsk == 0
+            if c0 < nh:
+                k = min(m, nh - c0)
+                packed[c0:c0 + k] = pk[:k]
+                lens[c0:c0 + k] = ln[:k]
+            dp[c0:c0 + m].copy_(torch.from_numpy(pk.view(np.int32)))
+            dl[c0:c0 + m].copy_(torch.from_numpy(ln))
             if c0 == 0:
                 assert np.array_equal(buf[:slice_reads * rl], sample), "the slice is not the head of the batch"
         del buf
-        dp = torch.from_numpy(packed.view(np.int32)).cuda()
-        dl = torch.from_numpy(lens).cuda()
+        torch.cuda.synchronize()
         lap("generate + pack + upload reads", t0)
 
         cw = ix.counter_words(G)
@@ -204,10 +217,23 @@ def run(genomes=15000, genome_len=3_450_000, n_reads=20_000_000, rl=150, slice_r
         checks["eight_shards_add_up"] = same(acc, whole)
         lap("device queries + additivity checks", t0)
         t0 = time.time()
-        nh = min(n_reads, 6_000_000)                                      # the host-fed door on a part of the batch
-        hq = ix.query_packed(packed[:nh], lens[:nh], rl, G)
+        # the host-fed door on the WHOLE shard: tight rows in page-locked memory -> H2D in chunks, widened and classified
+        # while the next chunk arrives -> rcount back narrow and widened on the host (SURVEY 8(d)'s bracket)
+        out = ix.counts_out(G, pinned=True)
+        ix.query_packed_tight(hp[:1 << 16], hl[:1 << 16], rl, G, out=out)
+        ts = []
+        for _ in range(2):
+            t1 = time.time()
+            hq = ix.query_packed_tight(hp, hl, rl, G, out=out)
+            ts.append(time.time() - t1)
+        checks["host_fed_door_whole_shard_equals_device_door"] = same(hq, whole)
+        rec["host_fed_ms_runs"] = [round(x * 1e3, 1) for x in ts]
+        rec["host_fed_Mreads_s"] = round(n_reads / min(ts) / 1e6, 1)
+        del out, hq
+        hq = ix.query_packed(packed[:nh], lens[:nh], rl, G)               # word rows from pageable memory, a part of the batch
         checks["host_fed_door_equals_device_door"] = same(hq, device_query(0, nh))
-        lap("host-fed door", t0)
+        del hq
+        lap("host-fed doors", t0)
 
         # ---- the oracle on the slice, against the sub-index
         t0 = time.time()
@@ -239,7 +265,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--genomes", type=int, default=15000)
     ap.add_argument("--genome-len", type=int, default=3_450_000)
-    ap.add_argument("--reads", type=int, default=20_000_000)
+    ap.add_argument("--reads", type=int, default=125_000_000, help="reads of the shard, ONE launch (configs[4]: 1 B reads over 8 GPUs)")
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "cfg4.json"))
     ap.add_argument("--fit", action="store_true", help="shrink --genome-len to what this box's host memory can build")
