@@ -118,6 +118,9 @@ def main():
                     help="skip the CPU oracle leg and its parity gate (used under rocprofv3 so that every "
                          "classify launch in the trace is a full-size timed step)")
     ap.add_argument("--no-host-fed", action="store_true", help="skip the PCIe-inclusive leg (cq_query_packed)")
+    ap.add_argument("--pipe-trace", default=None,
+                    help="host-fed leg: one more query with CAMMIQ_PIPE_TRACE=<this file> (the library's own event timeline; "
+                         "summarise with tools/pipe_trace.py), after the measured ones")
     ap.add_argument("--no-calibrate", action="store_true", help="skip the board calibrators (cq_calibrate, ~1 s before the timed region)")
     ap.add_argument("--multi-leg", choices=["auto", "on", "off"], default="auto",
                     help="N = 1 only: also run the same host-fed query through cq_multi_load / cq_multi_query_packed_tight (one "
@@ -436,6 +439,9 @@ def main():
                 roof["board"] = {
                     "gather_ceiling_here_Glines_s": round(calib["gather16_Glines_s"], 3),
                     "gather_mix_here_Glines_s": round(calib["gather16_mix_Glines_s"], 3),
+                    "chase_here_Glines_s": round(calib["chase16_Glines_s"], 3),
+                    "chase_latency_ns": round(calib["chase_latency_ns"], 1),
+                    "shader_clock_MHz_chase": round(calib["clock_MHz_chase"], 1),
                     "shader_clock_MHz_gather": round(calib["clock_MHz_gather"], 1),
                     "shader_clock_MHz_mix": round(calib["clock_MHz_mix"], 1),
                     "blocks_per_cu_best": [calib["gather_blocks_per_cu"], calib["mix_blocks_per_cu"]],
@@ -443,7 +449,9 @@ def main():
                     "what": "cq_calibrate on this run's board, before the timed region: random 16-byte loads from the "
                             "handle's own table (4 in flight per lane, best of 4/6/8 workgroups per CU); mix = the same "
                             "with a returnless atomic per 16 loads into an rcount-sized array and LDS stores/reads beside "
-                            "them; clocks = shader cycles per 100 MHz tick inside those kernels (median over workgroups)"}
+                            "them; chase = DEPENDENT random 16-byte loads (one in flight per lane) at 6 workgroups per CU, latency = "
+                            "lanes in flight / rate: what a latency-hiding kernel follows from board to board; clocks = shader "
+                            "cycles per 100 MHz tick inside those kernels (median over workgroups)"}
                 if ent and ent.get("fetch_bytes_per_launch"):
                     lines = float(ent["fetch_bytes_per_launch"]) / 64.0 / (k_ms * 1e-3)
                     roof["gather_ceiling_frac_here"] = round(lines / (calib["gather16_Glines_s"] * 1e9), 5)
@@ -501,6 +509,10 @@ def main():
                         "block; rcount comes back as one byte per leaf + an escape list and is widened into the caller's pinned "
                         "uint32 arrays by host threads while later pieces arrive (SURVEY 8(d) bracket, = the reference's "
                         "Time-for-query bracket); best of 3"}
+            if args.pipe_trace:
+                os.environ["CAMMIQ_PIPE_TRACE"] = args.pipe_trace
+                ix.query_packed_tight(h_packed[0], h_lens[0], rl, G, out=out)
+                os.environ.pop("CAMMIQ_PIPE_TRACE")
             # one query of batch 0 alone must agree with itself through both doors
             ctr.zero_(); rcd.zero_()
             ix.query_device(cq.MODE_P, d_packed[0].data_ptr(), d_lens[0].data_ptr(), n, sw, rl, G, ctr.data_ptr(),

@@ -42,7 +42,8 @@ class _LaunchInfo(C.Structure):
 class _Calibration(C.Structure):
     _fields_ = [("gather16_Glines_s", C.c_double), ("gather16_mix_Glines_s", C.c_double), ("clock_MHz_gather", C.c_double),
                 ("clock_MHz_mix", C.c_double), ("table_bytes", C.c_double), ("seconds", C.c_double),
-                ("gather_blocks_per_cu", C.c_int32), ("mix_blocks_per_cu", C.c_int32)]
+                ("gather_blocks_per_cu", C.c_int32), ("mix_blocks_per_cu", C.c_int32),
+                ("chase16_Glines_s", C.c_double), ("chase_latency_ns", C.c_double), ("clock_MHz_chase", C.c_double)]
 
 
 class _Counts(C.Structure):

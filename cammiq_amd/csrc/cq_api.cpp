@@ -33,6 +33,7 @@
 
 #include "cq_index.hpp"
 #include "cq_kernels.h"
+#include "cq_layout_gpu.h"
 
 namespace {
 
@@ -192,9 +193,9 @@ struct PipeTrace {
                 float ms = 0.f;
                 if (hipEventSynchronize(m.ev) == hipSuccess && first && hipEventElapsedTime(&ms, first, m.ev) == hipSuccess) { if (f) fprintf(f, "dev  %-14s %3d %10.3f\n", m.name.c_str(), m.chunk, ms); }
                 else (void)hipGetLastError();
-                (void)hipEventDestroy(m.ev);
             } else if (f) fprintf(f, "host %-14s %3d %10.3f\n", m.name.c_str(), m.chunk, m.host_ms);
         }
+        for (auto &m : marks) if (m.ev) (void)hipEventDestroy(m.ev);   // (after the loop: `first` is one of them)
         if (f) fclose(f);
         marks.clear();
     }
@@ -216,7 +217,24 @@ struct HostIndex {
     uint64_t n_trie_nodes = 0;
     bool from_cache = false;
     uint32_t doubly_flag[2] = {0, 1};
+    // The table is laid out on the device (cq_layout_gpu.hip): img.table stays empty, the decoded keys and their final
+    // trie codes wait here until every handle has uploaded them.  0 = host layout; 1 = device; 2 = device, and the host
+    // builder's image is built too and compared byte for byte (CAMMIQ_GPU_LAYOUT=verify: tests).
+    int gpu_layout = 0;
+    cq::RawVec<uint32_t> vals;
+    std::mutex mu;            // cq_multi: several uploading threads share this object
+    bool host_table_built = false;
 };
+
+// CAMMIQ_GPU_LAYOUT: 0 = host builder, 1 = device (any size), verify = device + host, compared; unset = device from
+// 65 536 entries on (below, the host builder is done before the first kernel would have launched).
+int gpu_layout_mode(uint64_t n_entries)
+{
+    const char *v = getenv("CAMMIQ_GPU_LAYOUT");
+    if (v && !strcmp(v, "verify")) return 2;
+    if (v && v[0]) return atoi(v) != 0 ? 1 : 0;
+    return n_entries >= (1u << 16) ? 1 : 0;
+}
 
 }  // namespace
 
@@ -443,8 +461,8 @@ int upload(cq_index *ix)
     hipDeviceProp_t prop;
     CQ_HIP(hipGetDeviceProperties(&prop, ix->device));
     ix->n_cus = prop.multiProcessorCount;
-    const cq::FlatImage &img = ix->H->img;
-    const size_t sb = img.table_words * sizeof(uint32_t);
+    HostIndex &H = *ix->H;
+    cq::FlatImage &img = H.img;
     const size_t nb = img.nodes.size() * sizeof(cq::Node);
     const size_t nl = img.leaf_r1.size();
     const bool timing = getenv("CAMMIQ_LOAD_TIMING") != nullptr;
@@ -454,20 +472,83 @@ int upload(cq_index *ix)
         if (timing) fprintf(stderr, "[cq_index_load]   %-22s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(n - t_up).count());
         t_up = n;
     };
-    CQ_HIP(hipMalloc(&ix->d_slots, sb));
     CQ_HIP(hipMalloc(&ix->d_nodes, nb));
     CQ_HIP(hipMalloc(&ix->d_leaf_rids, std::max<size_t>(nl, 1) * sizeof(uint2)));
-    up_lap("hipMalloc (image)");
-    CQ_HIP(upload_array(ix->d_slots, img.table.get(), sb));
     CQ_HIP(upload_array(ix->d_nodes, img.nodes.data(), nb));
-    up_lap("table + nodes");
     // leaf refIDs: (refID1, refID2) pairs interleaved straight into the page-locked pieces (no 8-byte-per-leaf staging array)
     CQ_HIP(upload_pieces(ix->d_leaf_rids, nullptr, nl * sizeof(uint2), [&img](char *p, size_t off, size_t n) {
         uint2 *o = (uint2 *)p;
         const size_t i0 = off / sizeof(uint2), cnt = n / sizeof(uint2);
         for (size_t i = 0; i < cnt; i++) o[i] = make_uint2(img.leaf_r1[i0 + i], img.leaf_r2[i0 + i]);
     }));
-    up_lap("leaf refIDs");
+    up_lap("nodes + leaf refIDs");
+    bool on_device = false;
+    if (H.gpu_layout) {
+        // ---- the table is laid out here, in HBM, from the decoded keys and their trie codes (cq_layout_gpu.hip)
+        const uint64_t nb_u = H.tab[0].bucket_key.size(), nb_d = H.tab[1].bucket_key.size(), ne = nb_u + nb_d;
+        uint64_t *d_keys = nullptr;
+        uint32_t *d_vals = nullptr;
+        cq::DeviceLayoutResult res;
+        bool unsupported = false;
+        hipError_t e = hipMalloc((void **)&d_keys, std::max<uint64_t>(ne, 1) * 8);
+        if (e == hipSuccess) e = hipMalloc((void **)&d_vals, std::max<uint64_t>(ne, 1) * 4);
+        if (e == hipSuccess && nb_u) e = upload_array(d_keys, H.tab[0].bucket_key.data(), nb_u * 8);
+        if (e == hipSuccess && nb_d) e = upload_array(d_keys + nb_u, H.tab[1].bucket_key.data(), nb_d * 8);
+        if (e == hipSuccess && ne) e = upload_array(d_vals, H.vals.data(), ne * 4);
+        up_lap("keys + codes");
+        if (e == hipSuccess)
+            e = cq::layout_table_on_device(d_keys, d_vals, nb_u, nb_d, img.hash_len, img.minimizer_len, (uint32_t)img.n_buckets,
+                                           (const uint2 *)ix->d_leaf_rids, ix->n_cus, res, unsupported);
+        if (d_keys) (void)hipFree(d_keys);
+        if (d_vals) (void)hipFree(d_vals);
+        up_lap("device layout");
+        if (e == hipSuccess && res.limit) return fail(CQ_ERR_LIMIT, "table would exceed 2^32 buckets");
+        if (e == hipSuccess && !unsupported) {
+            on_device = true;
+            ix->d_slots = res.d_table;
+            std::lock_guard<std::mutex> lk(H.mu);   // (every handle of a cq_multi computes the same numbers)
+            img.n_buckets_alloc = res.n_buckets_alloc;
+            img.table_words = res.n_buckets_alloc * CQ_BUCKET_WORDS;
+            img.n_keys = res.n_keys;
+            img.n_overflowed = res.n_overflowed;
+            img.max_chain = res.max_chain;
+        } else (void)hipGetLastError();   // out of device memory for the workspace, or a home group the device path leaves to the host
+    }
+    if (!on_device || H.gpu_layout == 2) {
+        // the host builder's image: handles without the device layout, its fall-back, and the reference `verify` compares with
+        if (H.gpu_layout) {
+            std::lock_guard<std::mutex> lk(H.mu);
+            if (!H.host_table_built) {
+                const cq::DeviceLayoutResult dev_stats = [&] { cq::DeviceLayoutResult r; r.n_buckets_alloc = img.n_buckets_alloc; r.n_keys = img.n_keys; r.n_overflowed = img.n_overflowed; r.max_chain = img.max_chain; return r; }();
+                std::string err;
+                int rc = cq::finish_image_host(H.tab[0], H.tab[1], H.vals, img, err);
+                if (rc != CQ_OK) return fail(rc, err);
+                H.host_table_built = true;
+                up_lap("host layout");
+                if (on_device && (dev_stats.n_buckets_alloc != img.n_buckets_alloc || dev_stats.n_keys != img.n_keys ||
+                                  dev_stats.n_overflowed != img.n_overflowed || dev_stats.max_chain != img.max_chain))
+                    return fail(CQ_ERR_FORMAT, "device layout: statistics differ from the host builder's (buckets " + std::to_string(dev_stats.n_buckets_alloc) + "/" +
+                                                   std::to_string(img.n_buckets_alloc) + ", keys " + std::to_string(dev_stats.n_keys) + "/" + std::to_string(img.n_keys) +
+                                                   ", overflowed " + std::to_string(dev_stats.n_overflowed) + "/" + std::to_string(img.n_overflowed) + ", max chain " +
+                                                   std::to_string(dev_stats.max_chain) + "/" + std::to_string(img.max_chain) + ")");
+            }
+        }
+        const size_t sb = img.table_words * sizeof(uint32_t);
+        if (on_device) {   // verify: the device's table against the host builder's, word for word
+            std::vector<uint32_t> got(img.table_words);
+            CQ_HIP(hipMemcpy(got.data(), ix->d_slots, sb, hipMemcpyDeviceToHost));
+            for (size_t w = 0; w < img.table_words; w++)
+                if (got[w] != img.table[w])
+                    return fail(CQ_ERR_FORMAT, "device layout differs from the host builder's image at bucket " + std::to_string(w / CQ_BUCKET_WORDS) + " word " +
+                                                   std::to_string(w % CQ_BUCKET_WORDS) + ": " + std::to_string(got[w]) + " vs " + std::to_string(img.table[w]));
+            up_lap("verify (equal)");
+        } else {
+            CQ_HIP(hipMalloc(&ix->d_slots, sb));
+            CQ_HIP(upload_array(ix->d_slots, img.table.get(), sb));
+            up_lap("table");
+        }
+    }
+    const size_t sb = img.table_words * sizeof(uint32_t);
     CQ_HIP(hipMalloc((void **)&ix->d_ovf_count, sizeof(uint32_t)));
     CQ_HIP(hipMalloc((void **)&ix->d_stamps, 8 * sizeof(uint64_t)));
     CQ_HIP(hipMemset(ix->d_stamps, 0, 8 * sizeof(uint64_t)));
@@ -500,7 +581,7 @@ struct LoadTimer {
 
 // Decode + lay out (or read the image cache): everything of cq_index_load that happens on the
 // host.  budget = bytes of HBM the table may take (1e30 = unlimited).
-int prepare_host(const char *path_u, const char *path_d, double budget, std::shared_ptr<HostIndex> &out, LoadTimer &lt)
+int prepare_host(const char *path_u, const char *path_d, double budget, std::shared_ptr<HostIndex> &out, LoadTimer &lt, bool for_device)
 {
     std::shared_ptr<HostIndex> H(new (std::nothrow) HostIndex());
     if (!H) return fail(CQ_ERR_NOMEM, "out of memory");
@@ -540,12 +621,17 @@ int prepare_host(const char *path_u, const char *path_d, double budget, std::sha
         if (keys / kpb * 64.0 > budget) kpb = std::min(3.2, keys * 64.0 / budget);
         if (kpb_override > 0.0) kpb = kpb_override;
         const uint32_t m_len = m_override ? cq_minimizer_len(H->tab[0].hash_len, std::min<uint32_t>(m_override, CQ_MAX_MINIMIZER)) : 0u;
-        int rc = cq::build_image(H->tab[0], H->tab[1], kpb, m_len, H->img, err);
+        // a handle on a GPU has its table laid out THERE (upload(): cq_layout_gpu.hip); the image cache and handles without
+        // a device need the host builder's image
+        H->gpu_layout = (for_device && !stamped) ? gpu_layout_mode((uint64_t)keys) : 0;
+        int rc = H->gpu_layout ? cq::prepare_image(H->tab[0], H->tab[1], kpb, m_len, H->img, H->vals, err)
+                               : cq::build_image(H->tab[0], H->tab[1], kpb, m_len, H->img, err);
         if (rc != CQ_OK) return fail(rc, err);
-        lt.lap("layout");
-        // bucket/node arrays of the decode stage are no longer needed; leaves are (cq_index_leaves)
+        lt.lap(H->gpu_layout ? "layout (host part)" : "layout");
+        // bucket/node arrays of the decode stage are no longer needed; leaves are (cq_index_leaves).  With the device
+        // layout the keys wait for their upload (release_layout_inputs).
         for (int t = 0; t < 2; t++) {
-            cq::RawVec<uint64_t>().swap(H->tab[t].bucket_key);
+            if (!H->gpu_layout) cq::RawVec<uint64_t>().swap(H->tab[t].bucket_key);
             cq::RawVec<uint32_t>().swap(H->tab[t].bucket_code);
             cq::RawVec<cq::Node>().swap(H->tab[t].nodes);
         }
@@ -566,6 +652,9 @@ int prepare_host(const char *path_u, const char *path_d, double budget, std::sha
 // The image now lives in HBM: drop the host copy (cq_index_probe needs a CQ_DEVICE_NONE handle).
 void drop_host_image(HostIndex &H)
 {
+    // what the device layout was fed from (every handle has uploaded it by now)
+    for (int t = 0; t < 2; t++) cq::RawVec<uint64_t>().swap(H.tab[t].bucket_key);
+    cq::RawVec<uint32_t>().swap(H.vals);
     // Giving several GB back to the OS takes hundreds of ms (0.4 s for configs[1]'s 3.2 GB table): a thread of its
     // own does it while cq_index_load returns.
     struct Dead { cq::HugeWords table; std::vector<cq::Node> nodes; std::vector<uint32_t> r1, r2; };
@@ -615,7 +704,7 @@ int cq_index_load(const char *path_u, const char *path_d, int device, cq_index *
     cq_index *ix = new (std::nothrow) cq_index();
     if (!ix) return fail(CQ_ERR_NOMEM, "out of memory");
     LoadTimer lt;
-    int rc = prepare_host(path_u, path_d, device >= 0 ? table_budget(device) : 1e30, ix->H, lt);
+    int rc = prepare_host(path_u, path_d, device >= 0 ? table_budget(device) : 1e30, ix->H, lt, device >= 0);
     if (rc != CQ_OK) { delete ix; return rc; }
     ix->device = device;
     if (device >= 0) {
@@ -807,6 +896,32 @@ int cq_calibrate(cq_index *ix, cq_calibration *out)
             }
             if (mix) { out->gather16_mix_Glines_s = best; out->clock_MHz_mix = best_clock; out->mix_blocks_per_cu = best_occ; }
             else { out->gather16_Glines_s = best; out->clock_MHz_gather = best_clock; out->gather_blocks_per_cu = best_occ; }
+        }
+        {   // dependent loads at the classify kernel's residency (6 workgroups per CU)
+            const int grid = ix->n_cus * 6, iters = 512;
+            CQ_HIPC(cq::launch_calib_chase((const uint4 *)ix->d_slots, n_units, 16, d_stamps, d_sink, grid, nullptr));   // warm
+            double best = 0.0, clock = 0.0;
+            for (int rep = 0; rep < 3; rep++) {
+                CQ_HIPC(hipEventRecord(e0, nullptr));
+                CQ_HIPC(cq::launch_calib_chase((const uint4 *)ix->d_slots, n_units, iters, d_stamps, d_sink, grid, nullptr));
+                CQ_HIPC(hipEventRecord(e1, nullptr));
+                CQ_HIPC(hipEventSynchronize(e1));
+                float ms = 0.f;
+                CQ_HIPC(hipEventElapsedTime(&ms, e0, e1));
+                const double rate = (double)grid * 256.0 * iters / (ms * 1e-3) / 1e9;
+                if (rate > best) {
+                    best = rate;
+                    CQ_HIPC(hipMemcpy(stamps.data(), d_stamps, (size_t)grid * 16, hipMemcpyDeviceToHost));
+                    std::vector<double> mhz;
+                    for (int b = 0; b < grid; b++)
+                        if (stamps[2 * b + 1]) mhz.push_back(100.0 * (double)stamps[2 * b] / (double)stamps[2 * b + 1]);
+                    std::sort(mhz.begin(), mhz.end());
+                    clock = mhz.empty() ? 0.0 : mhz[mhz.size() / 2];
+                }
+            }
+            out->chase16_Glines_s = best;
+            out->chase_latency_ns = best > 0.0 ? (double)grid * 256.0 / best : 0.0;   // lanes in flight / (1e9 loads per second) = ns
+            out->clock_MHz_chase = clock;
         }
     }
 done:
@@ -1542,7 +1657,7 @@ int cq_multi_load(const char *path_u, const char *path_d, const int *devices, in
     }
     LoadTimer lt;
     std::shared_ptr<HostIndex> H;
-    int rc = prepare_host(path_u, path_d, budget, H, lt);   // decode + layout ONCE
+    int rc = prepare_host(path_u, path_d, budget, H, lt, true);   // decode + (the host part of the) layout ONCE
     if (rc != CQ_OK) return rc;
     cq_multi *m = new (std::nothrow) cq_multi();
     if (!m) return fail(CQ_ERR_NOMEM, "out of memory");

@@ -83,5 +83,8 @@ hipError_t launch_narrow_rcount(const uint32_t *rc, uint64_t n, uint8_t *out8, u
 hipError_t launch_calib_gather(bool mix, const uint4 *tab, uint64_t n_units, int iters, uint32_t *atom, uint64_t n_atom,
                                uint64_t *stamps, uint32_t *sink, int grid, hipStream_t stream);
 
+// ... and the latency calibrator: every lane `iters` DEPENDENT random 16-byte loads (one in flight per lane).
+hipError_t launch_calib_chase(const uint4 *tab, uint64_t n_units, int iters, uint64_t *stamps, uint32_t *sink, int grid, hipStream_t stream);
+
 }  // namespace cq
 #endif

@@ -980,6 +980,35 @@ __global__ void __launch_bounds__(256) calib_gather_kernel(const uint4 *__restri
     if (acc == 0x12345678u) sink[0] = acc;
 }
 
+// The third calibrator: DEPENDENT random loads -- the address of a lane's next 16-byte load is a function of the quad
+// the last one returned (one load in flight per lane) -- at the classify kernel's residency.  The classify kernel is a
+// chain of such round trips per sub-tile (bucket quad -> compare -> bucket re-read -> trie node -> refIDs) hidden only
+// by the number of resident waves, so what a board's memory system answers a lone request in decides its time where the
+// saturated gather rate above is the same on every board.  rate = loads/s; latency = lanes in flight / rate.
+__global__ void __launch_bounds__(256) calib_chase_kernel(const uint4 *__restrict__ tab, uint64_t n_units, int iters,
+                                                          uint64_t *__restrict__ stamps, uint32_t *__restrict__ sink)
+{
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t s = (uint64_t)gid * 0x9E3779B97F4A7C15ull + 777;
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    uint32_t acc = 0;
+    for (int i = 0; i < iters; i++) {
+        s = s * 6364136223846793005ull + 1442695040888963407ull;
+        const uint4 v = tab[(uint64_t)(((__uint128_t)s * n_units) >> 64)];
+        s ^= ((uint64_t)v.x << 32) | v.y;   // the next address waits for this quad
+        acc += v.w;
+    }
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0) { stamps[2 * blockIdx.x] = c1 - c0; stamps[2 * blockIdx.x + 1] = r1 - r0; }
+    if (acc == 0x12345678u) sink[0] = acc;
+}
+
+hipError_t launch_calib_chase(const uint4 *tab, uint64_t n_units, int iters, uint64_t *stamps, uint32_t *sink, int grid, hipStream_t stream)
+{
+    hipLaunchKernelGGL(calib_chase_kernel, dim3((unsigned)grid), dim3(256), 0, stream, tab, n_units, iters, stamps, sink);
+    return hipGetLastError();
+}
+
 hipError_t launch_calib_gather(bool mix, const uint4 *tab, uint64_t n_units, int iters, uint32_t *atom, uint64_t n_atom,
                                uint64_t *stamps, uint32_t *sink, int grid, hipStream_t stream)
 {

@@ -289,7 +289,11 @@ int cq_last_launch_info(cq_index *idx, cq_launch_info *out);
  *                          4 / 6 / 8 workgroups per CU -- the ceiling the probe loop's bucket reads are held against
  *   gather16_mix_Glines_s  the same loads with a returnless global atomic per 16 loads into an rcount-sized array and
  *                          LDS stores / reads beside them (what the real kernel has and a plain gather lacks)
- *   clock_MHz_*            shader clock held DURING each of the two kernels: shader cycles / 100 MHz constant-clock
+ *   chase16_Glines_s       DEPENDENT random 16-byte loads per second (one in flight per lane: the next address is a
+ *                          function of the loaded quad) at 6 workgroups of 256 lanes per CU, the classify kernel's
+ *                          residency; chase_latency_ns = lanes in flight / that rate -- what the memory system answers
+ *                          a lone request in, which a latency-hiding kernel follows and a saturated gather does not show
+ *   clock_MHz_*            shader clock held DURING each of the kernels: shader cycles / 100 MHz constant-clock
  *                          ticks (s_memtime / s_memrealtime), median over workgroups
  * Not part of any query; a handle without a device returns CQ_ERR_NO_DEVICE.
  */
@@ -301,6 +305,9 @@ typedef struct cq_calibration {
     double table_bytes;         /* bytes of the table the loads were spread over */
     double seconds;             /* wall time the calibration took */
     int32_t gather_blocks_per_cu, mix_blocks_per_cu;   /* the occupancy that gave the best rate */
+    double chase16_Glines_s;
+    double chase_latency_ns;
+    double clock_MHz_chase;
 } cq_calibration;
 int cq_calibrate(cq_index *idx, cq_calibration *out);
 

@@ -22,7 +22,8 @@ from util import assert_same, build_index
 pytestmark = pytest.mark.gpu
 
 _KNOBS = ("CAMMIQ_MAX_SUB_PER_WAVE", "CAMMIQ_LDS_HIST_MAX", "CAMMIQ_KEYS_PER_BUCKET", "CAMMIQ_BLOCKS_PER_CU",
-          "CAMMIQ_PAIR_SLOTS", "CAMMIQ_FAST_R", "CAMMIQ_MINIMIZER_LEN", "CAMMIQ_NO_FIXED_SHAPE")
+          "CAMMIQ_PAIR_SLOTS", "CAMMIQ_FAST_R", "CAMMIQ_MINIMIZER_LEN", "CAMMIQ_NO_FIXED_SHAPE", "CAMMIQ_GPU_LAYOUT",
+          "CAMMIQ_NARROW_FROM", "CAMMIQ_NARROW_PIECE")
 
 
 def _draw(seed):
@@ -61,6 +62,12 @@ def _draw(seed):
         w["env"]["CAMMIQ_MINIMIZER_LEN"] = r.choice(["9", "13", "15", "17", "18", "18", "19", "21"])   # the table's address length (16 / 18 by size otherwise)
     if r.random() < 0.25:
         w["env"]["CAMMIQ_NO_FIXED_SHAPE"] = "1"                              # h = 26 at 100 / 150 bp: the generic instantiation instead
+    # round 4 (drawn last again): where the table is laid out -- on the device with the host builder's image compared
+    # byte for byte (verify), on the device, or on the host -- and rcount's narrow way back, through a ring of small pieces
+    w["env"]["CAMMIQ_GPU_LAYOUT"] = r.choice(["verify", "verify", "1", "0"])
+    if r.random() < 0.5:
+        w["env"]["CAMMIQ_NARROW_FROM"] = "1"
+        w["env"]["CAMMIQ_NARROW_PIECE"] = r.choice(["64", "1024", "65536"])
     return w
 
 
@@ -167,6 +174,10 @@ def _draw_generator(seed):
         w["env"]["CAMMIQ_MINIMIZER_LEN"] = r.choice(["14", "17", "18", "18", "20"])   # large tables use 18 by themselves
     if r.random() < 0.25:
         w["env"]["CAMMIQ_NO_FIXED_SHAPE"] = "1"
+    w["env"]["CAMMIQ_GPU_LAYOUT"] = r.choice(["verify", "verify", "1", "0"])    # round 4, drawn last: see _draw
+    if r.random() < 0.5:
+        w["env"]["CAMMIQ_NARROW_FROM"] = "1"
+        w["env"]["CAMMIQ_NARROW_PIECE"] = r.choice(["64", "4096", "65536"])
     return w
 
 
