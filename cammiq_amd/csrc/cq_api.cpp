@@ -224,6 +224,17 @@ struct HostIndex {
     cq::RawVec<uint32_t> vals;
     std::mutex mu;            // cq_multi: several uploading threads share this object
     bool host_table_built = false;
+    // the table's block in HBM, allocated by a thread of its own while the host part of the layout runs (hipMalloc of
+    // configs[4]'s 80 GB takes ~2 s): taken by the first handle on that device
+    std::thread prealloc_thread;
+    void *prealloc = nullptr;
+    uint64_t prealloc_buckets = 0;
+    int prealloc_device = -1;
+    ~HostIndex()
+    {
+        if (prealloc_thread.joinable()) prealloc_thread.join();
+        if (prealloc) { (void)hipSetDevice(prealloc_device); (void)hipFree(prealloc); }
+    }
 };
 
 // CAMMIQ_GPU_LAYOUT: 0 = host builder, 1 = device (any size), verify = device + host, compared; unset = device from
@@ -266,6 +277,7 @@ struct cq_index {
     } slot[kSlots];   // the host may enqueue the copies of the next chunks while the kernels of the chunks before are still running
     hipStream_t s_copy = nullptr, s_copy2 = nullptr, s_comp = nullptr;   // rows | lengths (their own DMA queue) | kernels
     hipStream_t s_widen = nullptr;   // tight rows -> word rows, beside the classify kernel of the chunk before (it leaves wave slots free)
+    hipStream_t s_d2h = nullptr;     // rcount's narrow pieces on their way back: a queue that never carries host-to-device rows
     uint64_t *d_ctr = nullptr; size_t ctr_cap = 0;
     uint32_t *d_rc = nullptr; size_t rc_cap = 0;
     void *h_bounce[2] = {nullptr, nullptr};
@@ -341,6 +353,7 @@ void release_device(cq_index *ix)
     if (ix->s_copy2) (void)hipStreamDestroy(ix->s_copy2);
     if (ix->s_comp) (void)hipStreamDestroy(ix->s_comp);
     if (ix->s_widen) (void)hipStreamDestroy(ix->s_widen);
+    if (ix->s_d2h) (void)hipStreamDestroy(ix->s_d2h);
     if (ix->d_ctr) (void)hipFree(ix->d_ctr);
     if (ix->d_rc) (void)hipFree(ix->d_rc);
     if (ix->pool) { ix->pool->stop(); delete ix->pool; ix->pool = nullptr; }
@@ -496,9 +509,17 @@ int upload(cq_index *ix)
         if (e == hipSuccess && nb_d) e = upload_array(d_keys + nb_u, H.tab[1].bucket_key.data(), nb_d * 8);
         if (e == hipSuccess && ne) e = upload_array(d_vals, H.vals.data(), ne * 4);
         up_lap("keys + codes");
+        void *pre = nullptr;
+        uint64_t pre_buckets = 0;
+        {   // the block allocated beside the host part, if it is on this device and nobody took it yet
+            std::lock_guard<std::mutex> lk(H.mu);
+            if (H.prealloc_thread.joinable()) H.prealloc_thread.join();
+            if (H.prealloc && H.prealloc_device == ix->device) { pre = H.prealloc; pre_buckets = H.prealloc_buckets; H.prealloc = nullptr; }
+        }
         if (e == hipSuccess)
             e = cq::layout_table_on_device(d_keys, d_vals, nb_u, nb_d, img.hash_len, img.minimizer_len, (uint32_t)img.n_buckets,
-                                           (const uint2 *)ix->d_leaf_rids, ix->n_cus, res, unsupported);
+                                           (const uint2 *)ix->d_leaf_rids, ix->n_cus, res, unsupported, pre, pre_buckets);
+        else if (pre) (void)hipFree(pre);
         if (d_keys) (void)hipFree(d_keys);
         if (d_vals) (void)hipFree(d_vals);
         up_lap("device layout");
@@ -581,8 +602,9 @@ struct LoadTimer {
 
 // Decode + lay out (or read the image cache): everything of cq_index_load that happens on the
 // host.  budget = bytes of HBM the table may take (1e30 = unlimited).
-int prepare_host(const char *path_u, const char *path_d, double budget, std::shared_ptr<HostIndex> &out, LoadTimer &lt, bool for_device)
+int prepare_host(const char *path_u, const char *path_d, double budget, std::shared_ptr<HostIndex> &out, LoadTimer &lt, int device)
 {
+    const bool for_device = device >= 0;
     std::shared_ptr<HostIndex> H(new (std::nothrow) HostIndex());
     if (!H) return fail(CQ_ERR_NOMEM, "out of memory");
     const bool have_d = path_d && path_d[0];
@@ -624,6 +646,21 @@ int prepare_host(const char *path_u, const char *path_d, double budget, std::sha
         // a handle on a GPU has its table laid out THERE (upload(): cq_layout_gpu.hip); the image cache and handles without
         // a device need the host builder's image
         H->gpu_layout = (for_device && !stamped) ? gpu_layout_mode((uint64_t)keys) : 0;
+        if (H->gpu_layout && keys >= 1e7) {
+            // the table's size is known now (the hash range cq::prepare_image will choose, + the spill tail): allocate it
+            // beside the host part of the layout
+            uint64_t nbk = (uint64_t)(keys / kpb) + 1;
+            if (nbk < 16) nbk = 16;
+            HostIndex *hp = H.get();
+            hp->prealloc_device = device;
+            hp->prealloc_buckets = nbk + CQ_SPILL_TAIL;
+            hp->prealloc_thread = std::thread([hp] {
+                if (hipSetDevice(hp->prealloc_device) != hipSuccess || hipMalloc(&hp->prealloc, hp->prealloc_buckets * 64) != hipSuccess) {
+                    (void)hipGetLastError();
+                    hp->prealloc = nullptr;
+                }
+            });
+        }
         int rc = H->gpu_layout ? cq::prepare_image(H->tab[0], H->tab[1], kpb, m_len, H->img, H->vals, err)
                                : cq::build_image(H->tab[0], H->tab[1], kpb, m_len, H->img, err);
         if (rc != CQ_OK) return fail(rc, err);
@@ -652,14 +689,15 @@ int prepare_host(const char *path_u, const char *path_d, double budget, std::sha
 // The image now lives in HBM: drop the host copy (cq_index_probe needs a CQ_DEVICE_NONE handle).
 void drop_host_image(HostIndex &H)
 {
-    // what the device layout was fed from (every handle has uploaded it by now)
-    for (int t = 0; t < 2; t++) cq::RawVec<uint64_t>().swap(H.tab[t].bucket_key);
-    cq::RawVec<uint32_t>().swap(H.vals);
     // Giving several GB back to the OS takes hundreds of ms (0.4 s for configs[1]'s 3.2 GB table): a thread of its
     // own does it while cq_index_load returns.
-    struct Dead { cq::HugeWords table; std::vector<cq::Node> nodes; std::vector<uint32_t> r1, r2; };
+    // (with the device layout there is no table image; what goes back is what the layout was fed from: the decoded keys and
+    // their trie codes, 15 GB at configs[4]'s size, 0.7 s when freed in line)
+    struct Dead { cq::HugeWords table; std::vector<cq::Node> nodes; std::vector<uint32_t> r1, r2; cq::RawVec<uint64_t> k0, k1; cq::RawVec<uint32_t> vals; };
     std::shared_ptr<Dead> d(new (std::nothrow) Dead());
     if (!d) {   // no memory for the little carrier: free in place
+        for (int t = 0; t < 2; t++) cq::RawVec<uint64_t>().swap(H.tab[t].bucket_key);
+        cq::RawVec<uint32_t>().swap(H.vals);
         H.img.table.reset();
         std::vector<cq::Node>().swap(H.img.nodes);
         std::vector<uint32_t>().swap(H.img.leaf_r1);
@@ -667,6 +705,9 @@ void drop_host_image(HostIndex &H)
         return;
     }
     d->table = std::move(H.img.table);
+    d->k0.swap(H.tab[0].bucket_key);
+    d->k1.swap(H.tab[1].bucket_key);
+    d->vals.swap(H.vals);
     d->nodes.swap(H.img.nodes);
     d->r1.swap(H.img.leaf_r1);
     d->r2.swap(H.img.leaf_r2);
@@ -704,7 +745,7 @@ int cq_index_load(const char *path_u, const char *path_d, int device, cq_index *
     cq_index *ix = new (std::nothrow) cq_index();
     if (!ix) return fail(CQ_ERR_NOMEM, "out of memory");
     LoadTimer lt;
-    int rc = prepare_host(path_u, path_d, device >= 0 ? table_budget(device) : 1e30, ix->H, lt, device >= 0);
+    int rc = prepare_host(path_u, path_d, device >= 0 ? table_budget(device) : 1e30, ix->H, lt, device);
     if (rc != CQ_OK) { delete ix; return rc; }
     ix->device = device;
     if (device >= 0) {
@@ -1357,6 +1398,7 @@ int ensure_narrow(cq_index *ix, uint64_t nl)
     if (!ix->h_ring) CQ_HIP(hipHostMalloc((void **)&ix->h_ring, (size_t)kNarrowRing * kNarrowPiece, hipHostMallocDefault));
     for (auto &e : ix->ev_ring) if (!e) CQ_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     if (!ix->ev_narrow) CQ_HIP(hipEventCreateWithFlags(&ix->ev_narrow, hipEventDisableTiming));
+    if (!ix->s_d2h) CQ_HIP(hipStreamCreateWithFlags(&ix->s_d2h, hipStreamNonBlocking));
     if (ix->pool && ix->pool->th.size() != widen_threads()) { ix->pool->stop(); delete ix->pool; ix->pool = nullptr; }   // knob changed
     if (!ix->pool) {
         WidenPool *p = new (std::nothrow) WidenPool();
@@ -1389,10 +1431,11 @@ int fetch_rcount_narrow(cq_index *ix, uint64_t n_u, uint64_t n_d, uint32_t *dst_
     CQ_HIP(cq::launch_narrow_rcount(ix->d_rc, nl, ix->d_rc8, ix->d_esc, ix->d_esc_count, ix->esc_cap, ix->s_comp));
     CQ_HIP(hipEventRecord(ix->ev_narrow, ix->s_comp));
     if (tr) tr->dev("narrow_end", 0, ix->s_comp);
-    CQ_HIP(hipStreamWaitEvent(ix->s_copy, ix->ev_narrow, 0));
-    // the count of escapes rides on the second copy queue (it must follow the narrow kernel too)
-    hipStream_t s_small = ix->s_copy2 ? ix->s_copy2 : ix->s_copy;
-    if (ix->s_copy2) CQ_HIP(hipStreamWaitEvent(ix->s_copy2, ix->ev_narrow, 0));
+    // the pieces (and the count of escapes in front of them) come back on a queue of their own (CAMMIQ_D2H_ON_COPY=1: the
+    // rows' copy queue, as the first version of this path did -- A/B knob)
+    hipStream_t s_back = (getenv("CAMMIQ_D2H_ON_COPY") && atoi(getenv("CAMMIQ_D2H_ON_COPY"))) ? ix->s_copy : ix->s_d2h;
+    CQ_HIP(hipStreamWaitEvent(s_back, ix->ev_narrow, 0));
+    hipStream_t s_small = s_back;
     CQ_HIP(hipMemcpyAsync(ix->h_esc_count, ix->d_esc_count, sizeof(uint32_t), hipMemcpyDeviceToHost, s_small));
     uint64_t piece = kNarrowPiece;
     if (const char *v = getenv("CAMMIQ_NARROW_PIECE"))   // test knob: small pieces take a small rcount through the whole ring
@@ -1401,8 +1444,8 @@ int fetch_rcount_narrow(cq_index *ix, uint64_t n_u, uint64_t n_d, uint32_t *dst_
     auto piece_bytes = [&](uint64_t k) { return (size_t)std::min<uint64_t>(piece, nl - k * piece); };
     auto enqueue = [&](uint64_t k) -> hipError_t {
         hipError_t e = hipMemcpyAsync(ix->h_ring + (k % kNarrowRing) * piece, ix->d_rc8 + k * piece, piece_bytes(k),
-                                      hipMemcpyDeviceToHost, ix->s_copy);
-        return e != hipSuccess ? e : hipEventRecord(ix->ev_ring[k % kNarrowRing], ix->s_copy);
+                                      hipMemcpyDeviceToHost, s_back);
+        return e != hipSuccess ? e : hipEventRecord(ix->ev_ring[k % kNarrowRing], s_back);
     };
     for (uint64_t k = 0; k < np && k < (uint64_t)kNarrowRing; k++) CQ_HIP(enqueue(k));
     {   // wake the workers: they spin on `ready` from here on
@@ -1424,7 +1467,7 @@ int fetch_rcount_narrow(cq_index *ix, uint64_t n_u, uint64_t n_d, uint32_t *dst_
             if (bad == hipSuccess) bad = enqueue(k + kNarrowRing);
         }
     }
-    if (tr) { tr->dev("d2h_last_piece", (int)np, ix->s_copy); tr->host("pieces_copied", (int)np); }
+    if (tr) { tr->dev("d2h_last_piece", (int)np, s_back); tr->host("pieces_copied", (int)np); }
     while (P.workers_done.load(std::memory_order_acquire) < W) _mm_pause();
     if (tr) tr->host("widened", (int)np);
     if (bad != hipSuccess) return fail(CQ_ERR_HIP, std::string("narrow rcount copy: ") + hipGetErrorString(bad));
@@ -1657,7 +1700,7 @@ int cq_multi_load(const char *path_u, const char *path_d, const int *devices, in
     }
     LoadTimer lt;
     std::shared_ptr<HostIndex> H;
-    int rc = prepare_host(path_u, path_d, budget, H, lt, true);   // decode + (the host part of the) layout ONCE
+    int rc = prepare_host(path_u, path_d, budget, H, lt, devices[0]);   // decode + (the host part of the) layout ONCE
     if (rc != CQ_OK) return rc;
     cq_multi *m = new (std::nothrow) cq_multi();
     if (!m) return fail(CQ_ERR_NOMEM, "out of memory");

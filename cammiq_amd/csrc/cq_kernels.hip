@@ -454,20 +454,26 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(CQ_
 classify_kernel(DevIndex ix, QueryArgs a)
 {
     static_assert(SLOW || R * 4 <= 64, "a sub-tile's rows (R x <= 16 words) must fit one 16-byte load per lane");
-    static_assert((H == 0) == (RL == 0) && (H == 0) == (M == 0) && (H == 0 || (H >= 5 && H <= 31 && RL >= H && RL <= 255 && M <= H && M <= CQ_MAX_MINIMIZER)),
+    // RL > 0: the batch's longest read is exactly RL (row stride, windows and positions per read, all magics constant);
+    // RL < 0: only the row stride is fixed, -RL words (any batch of that stride: 101-, 125-, 151-bp reads -- what real
+    //         FASTQs hold -- keep h, m and the stride as constants and take the window counts as launch arguments).
+    static_assert((H == 0) == (RL == 0) && (H == 0) == (M == 0) &&
+                      (H == 0 || (H >= 5 && H <= 31 && M <= H && M <= CQ_MAX_MINIMIZER && ((RL >= H && RL <= 255) || (RL <= -1 && RL >= -16)))),
                   "H, RL and M are fixed together");
-    constexpr bool FX = H != 0;
-    constexpr uint32_t cM = M, cW = FX ? RL - H + 1 : 0, cP = cW + (H - cM);
+    constexpr bool FX = H != 0;       // hash and minimizer length fixed
+    constexpr bool FXL = RL > 0;      // ... and the batch's exact shape
+    constexpr uint32_t cSW = RL > 0 ? (uint32_t)(RL + 15) / 16 : (RL < 0 ? (uint32_t)(-RL) : 0u);
+    constexpr uint32_t cM = M, cW = FXL ? RL - H + 1 : 0, cP = cW + (H - cM);
     constexpr uint32_t cN = H - cM + 1;   // m-mers per window
     extern __shared__ __align__(16) uint32_t smem[];
-    const uint32_t sw = FX ? (uint32_t)(RL + 15) / 16 : a.stride_words, swp = sw | 1u;
+    const uint32_t sw = FX ? cSW : a.stride_words, swp = sw | 1u;
     const uint32_t G1 = a.n_genomes + 1;
     const uint32_t h = FX ? (uint32_t)H : ix.hash_len, m = FX ? cM : ix.minimizer_len, nphi = h - m + 1;
-    const uint32_t wmax = FX ? cW : a.wmax, pmax = FX ? cP : a.pmax;
-    const uint32_t pstride = FX ? (((cP + kPrePos - 1u) / kPrePos * kPrePos) | 1u) : a.pstride;
-    const uint32_t magic_s = FX ? magic_of_c((RL + 15) / 16) : a.magic_s;
-    const uint32_t magic_pp = FX ? magic_of_c((cP + kPrePos - 1u) / kPrePos) : a.magic_pp;
-    const uint32_t magic_w = FX ? magic_of_c((cW + kWinPerLane - 1u) / kWinPerLane) : a.magic_w;
+    const uint32_t wmax = FXL ? cW : a.wmax, pmax = FXL ? cP : a.pmax;
+    const uint32_t pstride = FXL ? (((cP + kPrePos - 1u) / kPrePos * kPrePos) | 1u) : a.pstride;
+    const uint32_t magic_s = FX ? magic_of_c(cSW) : a.magic_s;
+    const uint32_t magic_pp = FXL ? magic_of_c((cP + kPrePos - 1u) / kPrePos) : a.magic_pp;
+    const uint32_t magic_w = FXL ? magic_of_c((cW + kWinPerLane - 1u) / kWinPerLane) : a.magic_w;
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
     const SmemLayout L = smem_layout(R, CAP, sw, pstride, a.n_genomes, a.use_lds_hist != 0);
     uint32_t *mine = smem + wave * L.per_wave;
@@ -1035,7 +1041,10 @@ namespace {
 // cost HIP runtime calls (hipFuncSetAttribute + hipOccupancyMaxActiveBlocksPerMultiprocessor: tens of
 // microseconds, 24 x per host-fed query when asked per chunk), so their answers are kept per (device, variant,
 // LDS bytes): the first launch of a shape pays, later launches look up.
-enum Variant { kV8 = 0, kV4 = 1, kV8h26r100 = 2, kV8h26r150 = 3, kV8h26r100m18 = 4, kV8h26r150m18 = 5, kVSlow = 6, kNVariants = 7 };
+enum Variant { kV8 = 0, kV4 = 1, kV8h26r100 = 2, kV8h26r150 = 3, kV8h26r100m18 = 4, kV8h26r150m18 = 5,
+               // h = 26, m and the row stride fixed, lengths at run time: batches of 97..112 / 113..128 / 145..160 bases
+               kV8h26s7 = 6, kV8h26s8 = 7, kV8h26s10 = 8, kV8h26s7m18 = 9, kV8h26s8m18 = 10, kV8h26s10m18 = 11,
+               kVSlow = 12, kNVariants = 13 };
 
 const void *variant_fn(int v)
 {
@@ -1046,6 +1055,12 @@ const void *variant_fn(int v)
     case kV8h26r150: return (const void *)classify_kernel<8, kFastCAP, false, 26, 150, 16>;
     case kV8h26r100m18: return (const void *)classify_kernel<8, kFastCAP, false, 26, 100, 18>;
     case kV8h26r150m18: return (const void *)classify_kernel<8, kFastCAP, false, 26, 150, 18>;
+    case kV8h26s7: return (const void *)classify_kernel<8, kFastCAP, false, 26, -7, 16>;
+    case kV8h26s8: return (const void *)classify_kernel<8, kFastCAP, false, 26, -8, 16>;
+    case kV8h26s10: return (const void *)classify_kernel<8, kFastCAP, false, 26, -10, 16>;
+    case kV8h26s7m18: return (const void *)classify_kernel<8, kFastCAP, false, 26, -7, 18>;
+    case kV8h26s8m18: return (const void *)classify_kernel<8, kFastCAP, false, 26, -8, 18>;
+    case kV8h26s10m18: return (const void *)classify_kernel<8, kFastCAP, false, 26, -10, 18>;
     default: return (const void *)classify_kernel<kSlowR, kSlowCAP, true, 0, 0, 0>;
     }
 }
@@ -1126,6 +1141,12 @@ hipError_t launch_fast(int variant, const DevIndex &ix, QueryArgs &a, int n_cus,
         case kV8h26r150: launch_one<8, 26, 150, 16>(ix, a, (unsigned)grid, sm, stream); break;
         case kV8h26r100m18: launch_one<8, 26, 100, 18>(ix, a, (unsigned)grid, sm, stream); break;
         case kV8h26r150m18: launch_one<8, 26, 150, 18>(ix, a, (unsigned)grid, sm, stream); break;
+        case kV8h26s7: launch_one<8, 26, -7, 16>(ix, a, (unsigned)grid, sm, stream); break;
+        case kV8h26s8: launch_one<8, 26, -8, 16>(ix, a, (unsigned)grid, sm, stream); break;
+        case kV8h26s10: launch_one<8, 26, -10, 16>(ix, a, (unsigned)grid, sm, stream); break;
+        case kV8h26s7m18: launch_one<8, 26, -7, 18>(ix, a, (unsigned)grid, sm, stream); break;
+        case kV8h26s8m18: launch_one<8, 26, -8, 18>(ix, a, (unsigned)grid, sm, stream); break;
+        case kV8h26s10m18: launch_one<8, 26, -10, 18>(ix, a, (unsigned)grid, sm, stream); break;
         default: launch_one<8, 0, 0, 0>(ix, a, (unsigned)grid, sm, stream); break;
         }
         e = hipGetLastError();
@@ -1172,6 +1193,14 @@ hipError_t launch_classify(const DevIndex &ix, QueryArgs a, int n_cus, hipStream
     if (R == 8 && ix.hash_len == 26 && (ix.minimizer_len == 16 || ix.minimizer_len == 18) && !(nofix && atoi(nofix))) {
         int fx = -1;
         const bool m18 = ix.minimizer_len == 18;
+        // any batch of a common row stride keeps h, m and the stride as constants (101-, 125-, 151-bp reads: what real
+        // FASTQs hold); the two benchmark lengths have their whole shape folded in
+        const char *noshape = getenv("CAMMIQ_NO_STRIDE_SHAPE");   // A/B knob: only the exact-length instantiations
+        if (!(noshape && atoi(noshape))) {
+            if (a.stride_words == 7) fx = m18 ? kV8h26s7m18 : kV8h26s7;
+            if (a.stride_words == 8) fx = m18 ? kV8h26s8m18 : kV8h26s8;
+            if (a.stride_words == 10) fx = m18 ? kV8h26s10m18 : kV8h26s10;
+        }
         if (a.wmax == 100 - 26 + 1 && a.stride_words == 7) fx = m18 ? kV8h26r100m18 : kV8h26r100;
         if (a.wmax == 150 - 26 + 1 && a.stride_words == 10) fx = m18 ? kV8h26r150m18 : kV8h26r150;
         if (fx >= 0) {
@@ -1181,8 +1210,10 @@ hipError_t launch_classify(const DevIndex &ix, QueryArgs a, int n_cus, hipStream
         }
     }
     if (info) { info->reads_per_subtile = R; info->hit_slots = kFastCAP; info->lds_hist = (int)a.use_lds_hist; info->fixed_shape = (variant >= kV8h26r100 && variant != kVSlow) ? 1 : 0;
-                info->fixed_h = variant >= kV8h26r100 ? 26 : 0;
-                info->fixed_read_len = (variant == kV8h26r100 || variant == kV8h26r100m18) ? 100 : (variant == kV8h26r150 || variant == kV8h26r150m18) ? 150 : 0;
+                info->fixed_h = (variant >= kV8h26r100 && variant != kVSlow) ? 26 : 0;
+                // the template's RL argument: the exact read length, or minus the row stride in words when only that is fixed
+                info->fixed_read_len = (variant == kV8h26r100 || variant == kV8h26r100m18) ? 100 : (variant == kV8h26r150 || variant == kV8h26r150m18) ? 150
+                                       : (variant >= kV8h26s7 && variant <= kV8h26s10m18) ? -(int)a.stride_words : 0;
                 info->minimizer_len = (int)ix.minimizer_len;
                 info->blocks_per_cu = per_cu; }
     if (ev_start) { e = hipEventRecord(ev_start, stream); if (e != hipSuccess) return e; }

@@ -21,7 +21,10 @@ struct DeviceLayoutResult {
 // merged open-addressing table for a hash range of n_buckets exactly as finish_image_host does (byte-identical).
 // unsupported = true (and hipSuccess): a home bucket holds more keys than the device path sorts -- use the host builder.
 hipError_t layout_table_on_device(const uint64_t *d_keys, const uint32_t *d_vals, uint64_t nb_u, uint64_t nb_d, uint32_t h, uint32_t m,
-                                  uint32_t n_buckets, const uint2 *d_leaf_rids, int n_cus, DeviceLayoutResult &out, bool &unsupported);
+                                  uint32_t n_buckets, const uint2 *d_leaf_rids, int n_cus, DeviceLayoutResult &out, bool &unsupported,
+                                  void *prealloc = nullptr, uint64_t prealloc_buckets = 0);
+// prealloc: a hipMalloc'ed block of prealloc_buckets x 64 bytes the table may be built in (taken over, or freed when too
+// small): the 80 GB hipMalloc of a configs[4]-size table takes ~2 s, which the caller can spend beside the host part.
 
 }  // namespace cq
 #endif

@@ -363,12 +363,15 @@ def test_reads_per_sub_tile_do_not_change_the_result(tmp_path, monkeypatch, rl):
                 assert got["pairs"] == ref["pairs"]
 
 
-@pytest.mark.parametrize("rl", [100, 150])
+@pytest.mark.parametrize("rl", [100, 150, 101, 125, 151])
 def test_fixed_shape_instantiation_equals_the_generic_kernel(tmp_path, monkeypatch, rl):
     """h = 26 (CAMMiQ's default) with a batch whose longest read is 100 / 150 bp runs the instantiation that has hash
-    length and batch shape folded in as constants; CAMMIQ_NO_FIXED_SHAPE=1 forces the generic one.  Both against
-    the oracle: deep keys, mixed read lengths below the batch maximum (ragged windows), both modes, counters in
-    LDS and as global atomics."""
+    length and batch shape folded in as constants; a batch of any other length whose rows are 7, 8 or 10 words (97-112,
+    113-128, 145-160 bases: the 101-, 125-, 151-bp reads real FASTQs hold) runs the one with h, m and the row stride
+    folded in and the window counts as launch arguments (fixed_read_len = minus the stride); CAMMIQ_NO_FIXED_SHAPE=1
+    forces the generic one.  All against the oracle: deep keys, mixed read lengths below the batch maximum (ragged
+    windows), both modes, counters in LDS and as global atomics."""
+    want_rl = rl if rl in (100, 150) else -((rl + 15) // 16)
     gen = synth.clade_genomes(77, 3, 4, 4000, 0.03)
     u, d = synth.select_markers(gen, 26, 48, keep_every=2, seed=6)
     pu, pd = build_index(tmp_path, u, d, 26)
@@ -386,14 +389,14 @@ def test_fixed_shape_instantiation_equals_the_generic_kernel(tmp_path, monkeypat
                 got = ix.query(b, o, len(gen), mode=mode)
                 li = ix.last_launch_info()
                 assert li["fixed_shape"] == (0 if nofix == "1" else 1), li
-                assert li["fixed_read_len"] == (0 if nofix == "1" else rl) and li["reads_per_subtile"] == 8
+                assert li["fixed_read_len"] == (0 if nofix == "1" else want_rl) and li["reads_per_subtile"] == 8
                 assert li["lds_hist"] == (1 if hist != "0" else 0)
                 assert_same(got, ref, f"rl={rl} nofix={nofix} hist={hist} mode={mode}", rcount=(mode == cq.MODE_P))
                 assert got["pairs"] == ref["pairs"]
     # another hash length or another batch shape never takes it
     monkeypatch.delenv("CAMMIQ_NO_FIXED_SHAPE")
     ix = cq.Index(pu, pd, device=0)
-    ix.query(*synth.concat_reads(reads[:2000] + [b"ACGT" * 50]), len(gen))
+    ix.query(*synth.concat_reads(reads[:2000] + [b"ACGT" * 50]), len(gen))       # 200 bases: 13-word rows
     assert ix.last_launch_info()["fixed_shape"] == 0
 
 
