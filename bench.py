@@ -449,8 +449,8 @@ def main():
                     "what": "cq_calibrate on this run's board, before the timed region: random 16-byte loads from the "
                             "handle's own table (4 in flight per lane, best of 4/6/8 workgroups per CU); mix = the same "
                             "with a returnless atomic per 16 loads into an rcount-sized array and LDS stores/reads beside "
-                            "them; chase = DEPENDENT random 16-byte loads (one in flight per lane) at 6 workgroups per CU, latency = "
-                            "lanes in flight / rate: what a latency-hiding kernel follows from board to board; clocks = shader "
+                            "them; chase = DEPENDENT random 16-byte loads (one in flight per lane) from one wave per CU, latency = "
+                            "lanes in flight / rate: what the memory system answers a lone request in; clocks = shader "
                             "cycles per 100 MHz tick inside those kernels (median over workgroups)"}
                 if ent and ent.get("fetch_bytes_per_launch"):
                     lines = float(ent["fetch_bytes_per_launch"]) / 64.0 / (k_ms * 1e-3)

@@ -70,10 +70,9 @@ uint64_t chunk_reads()                           // ... CAMMIQ_CHUNK_READS overr
 }
 constexpr size_t kBounce = 16u << 20;            // pinned bounce buffer for D2H into pageable arrays
 constexpr int kSlots = 4;                        // staging slots of the host-fed pipeline
-// rcount comes back narrow (one byte per leaf + escapes, launch_narrow_rcount): pieces of kNarrowPiece bytes rotate over
-// a page-locked ring while a few host threads widen the piece before into the caller's uint32 arrays
-constexpr size_t kNarrowPiece = 4u << 20;
-constexpr int kNarrowRing = 8;
+// rcount comes back narrow (one byte per leaf + escapes): launch_narrow_rcount writes the bytes into page-locked host
+// memory segment by segment (cq::kNarrowSeg entries each) and flags every segment; a few host threads poll the flags and
+// widen the segments into the caller's uint32 arrays as they land
 constexpr uint64_t kNarrowFrom = 1u << 20;       // leaves; below, the plain uint32 copy is a fraction of a millisecond anyway
 
 // bytes -> uint32, entries [0, n): streaming stores where the destination allows (the 4 n bytes written are never
@@ -108,9 +107,8 @@ void widen_span(const uint8_t *src8, uint64_t a, uint64_t b, uint64_t n_u, uint3
     if (b > n_u) { const uint64_t s0 = std::max(a, n_u); widen_u8(src8 + (s0 - a), dst_d + (s0 - n_u), (size_t)(b - s0)); }
 }
 
-// A few host threads that sleep between queries and widen the pieces of one narrow rcount as the copy engine
-// delivers them (fetch_rcount_narrow).  Piece k lives in ring slot k % kNarrowRing; `ready` = pieces delivered so far;
-// fin[slot] counts the workers that are through with the piece in that slot, over the whole job.
+// A few host threads that sleep between queries and widen the segments of one narrow rcount as the GPU delivers them
+// (fetch_rcount_narrow).  flags[s] == epoch: segment s is in `narrow`; the threads take segments off a shared counter.
 struct WidenPool {
     std::vector<std::thread> th;
     std::mutex mu;
@@ -118,14 +116,16 @@ struct WidenPool {
     uint64_t job_seq = 0;
     bool quit = false;
     // the current job
-    const uint8_t *ring = nullptr;
-    uint64_t n = 0, n_u = 0, n_pieces = 0, piece = kNarrowPiece;
+    const uint8_t *narrow = nullptr;
+    const volatile uint32_t *flags = nullptr;
+    uint32_t epoch = 0;
+    uint64_t n = 0, n_u = 0, n_segments = 0, seg = 0;
     uint32_t *dst_u = nullptr, *dst_d = nullptr;
-    std::atomic<uint64_t> ready{0};
-    std::atomic<uint64_t> fin[kNarrowRing];
+    std::atomic<uint64_t> next{0};
     std::atomic<uint32_t> workers_done{0};
+    std::atomic<bool> abort{false};          // the kernel failed: stop waiting for flags
 
-    void run(unsigned t, unsigned W)
+    void run()
     {
         uint64_t seen = 0;
         for (;;) {
@@ -135,21 +135,21 @@ struct WidenPool {
                 if (quit) return;
                 seen = job_seq;
             }
-            for (uint64_t k = 0; k < n_pieces; k++) {
-                while (ready.load(std::memory_order_acquire) <= k) _mm_pause();
-                const uint64_t lo = k * piece, len = std::min<uint64_t>(piece, n - lo);
-                auto cut = [&](unsigned i) { return i >= W ? len : (len * i / W) & ~(uint64_t)63; };   // 64-entry cuts: aligned streaming stores
-                const uint64_t a = cut(t), b = cut(t + 1);
-                if (b > a) widen_span(ring + (k % kNarrowRing) * piece + a, lo + a, lo + b, n_u, dst_u, dst_d);
-                fin[k % kNarrowRing].fetch_add(1, std::memory_order_release);
+            for (;;) {
+                const uint64_t k = next.fetch_add(1, std::memory_order_relaxed);
+                if (k >= n_segments) break;
+                while (flags[k] != epoch && !abort.load(std::memory_order_relaxed)) _mm_pause();
+                std::atomic_thread_fence(std::memory_order_acquire);
+                if (abort.load(std::memory_order_relaxed)) break;
+                const uint64_t lo = k * seg, hi = std::min<uint64_t>(lo + seg, n);
+                widen_span(narrow + lo, lo, hi, n_u, dst_u, dst_d);
             }
             workers_done.fetch_add(1, std::memory_order_release);
         }
     }
     void start(unsigned W)
     {
-        for (auto &f : fin) f.store(0);
-        for (unsigned t = 0; t < W; t++) th.emplace_back([this, t, W] { run(t, W); });
+        for (unsigned t = 0; t < W; t++) th.emplace_back([this] { run(); });
     }
     void stop()
     {
@@ -277,7 +277,6 @@ struct cq_index {
     } slot[kSlots];   // the host may enqueue the copies of the next chunks while the kernels of the chunks before are still running
     hipStream_t s_copy = nullptr, s_copy2 = nullptr, s_comp = nullptr;   // rows | lengths (their own DMA queue) | kernels
     hipStream_t s_widen = nullptr;   // tight rows -> word rows, beside the classify kernel of the chunk before (it leaves wave slots free)
-    hipStream_t s_d2h = nullptr;     // rcount's narrow pieces on their way back: a queue that never carries host-to-device rows
     uint64_t *d_ctr = nullptr; size_t ctr_cap = 0;
     uint32_t *d_rc = nullptr; size_t rc_cap = 0;
     void *h_bounce[2] = {nullptr, nullptr};
@@ -285,9 +284,11 @@ struct cq_index {
     // rcount's narrow way back (fetch_rcount_narrow)
     uint8_t *d_rc8 = nullptr; size_t rc8_cap = 0;
     uint2 *d_esc = nullptr; uint32_t *d_esc_count = nullptr; uint32_t esc_cap = 0;
-    uint8_t *h_ring = nullptr;                 // kNarrowRing x kNarrowPiece, page-locked
+    uint8_t *h_narrow = nullptr; size_t narrow_cap = 0;   // page-locked: the kernel writes rcount's bytes here
+    uint32_t *h_flags = nullptr; size_t flags_cap = 0;    // page-locked: one word per segment + the final one
+    uint32_t *d_blocks_done = nullptr;
+    uint32_t narrow_epoch = 0;
     uint2 *h_esc = nullptr; uint32_t *h_esc_count = nullptr;
-    hipEvent_t ev_ring[kNarrowRing] = {};
     hipEvent_t ev_narrow = nullptr;
     WidenPool *pool = nullptr;
     PipeTrace *trace = nullptr;                // CAMMIQ_PIPE_TRACE: the query being traced (classify_range .. fetch_counts)
@@ -353,17 +354,17 @@ void release_device(cq_index *ix)
     if (ix->s_copy2) (void)hipStreamDestroy(ix->s_copy2);
     if (ix->s_comp) (void)hipStreamDestroy(ix->s_comp);
     if (ix->s_widen) (void)hipStreamDestroy(ix->s_widen);
-    if (ix->s_d2h) (void)hipStreamDestroy(ix->s_d2h);
     if (ix->d_ctr) (void)hipFree(ix->d_ctr);
     if (ix->d_rc) (void)hipFree(ix->d_rc);
     if (ix->pool) { ix->pool->stop(); delete ix->pool; ix->pool = nullptr; }
     if (ix->d_rc8) (void)hipFree(ix->d_rc8);
     if (ix->d_esc) (void)hipFree(ix->d_esc);
     if (ix->d_esc_count) (void)hipFree(ix->d_esc_count);
-    if (ix->h_ring) (void)hipHostFree(ix->h_ring);
+    if (ix->h_narrow) (void)hipHostFree(ix->h_narrow);
+    if (ix->h_flags) (void)hipHostFree(ix->h_flags);
+    if (ix->d_blocks_done) (void)hipFree(ix->d_blocks_done);
     if (ix->h_esc) (void)hipHostFree(ix->h_esc);
     if (ix->h_esc_count) (void)hipHostFree(ix->h_esc_count);
-    for (hipEvent_t e : ix->ev_ring) if (e) (void)hipEventDestroy(e);
     if (ix->ev_narrow) (void)hipEventDestroy(ix->ev_narrow);
 }
 
@@ -938,8 +939,8 @@ int cq_calibrate(cq_index *ix, cq_calibration *out)
             if (mix) { out->gather16_mix_Glines_s = best; out->clock_MHz_mix = best_clock; out->mix_blocks_per_cu = best_occ; }
             else { out->gather16_Glines_s = best; out->clock_MHz_gather = best_clock; out->gather_blocks_per_cu = best_occ; }
         }
-        {   // dependent loads at the classify kernel's residency (6 workgroups per CU)
-            const int grid = ix->n_cus * 6, iters = 512;
+        {   // dependent loads, one wave per CU: far below what saturates the memory system, so lanes / rate = latency
+            const int grid = ix->n_cus, iters = 2048;
             CQ_HIPC(cq::launch_calib_chase((const uint4 *)ix->d_slots, n_units, 16, d_stamps, d_sink, grid, nullptr));   // warm
             double best = 0.0, clock = 0.0;
             for (int rep = 0; rep < 3; rep++) {
@@ -949,7 +950,7 @@ int cq_calibrate(cq_index *ix, cq_calibration *out)
                 CQ_HIPC(hipEventSynchronize(e1));
                 float ms = 0.f;
                 CQ_HIPC(hipEventElapsedTime(&ms, e0, e1));
-                const double rate = (double)grid * 256.0 * iters / (ms * 1e-3) / 1e9;
+                const double rate = (double)grid * 64.0 * iters / (ms * 1e-3) / 1e9;
                 if (rate > best) {
                     best = rate;
                     CQ_HIPC(hipMemcpy(stamps.data(), d_stamps, (size_t)grid * 16, hipMemcpyDeviceToHost));
@@ -961,7 +962,7 @@ int cq_calibrate(cq_index *ix, cq_calibration *out)
                 }
             }
             out->chase16_Glines_s = best;
-            out->chase_latency_ns = best > 0.0 ? (double)grid * 256.0 / best : 0.0;   // lanes in flight / (1e9 loads per second) = ns
+            out->chase_latency_ns = best > 0.0 ? (double)grid * 64.0 / best : 0.0;   // lanes in flight / (1e9 loads per second) = ns
             out->clock_MHz_chase = clock;
         }
     }
@@ -1205,17 +1206,20 @@ int classify_range(cq_index *ix, int mode, const Feed &f, uint64_t lo, uint64_t 
     // A/B/A/B on one box: the copy queue is the critical path, the last kernel's 0.9 ms is all a ramp can shorten.)
     // Round 4: the copies are the critical path (25 B per read at the link's ~55 GB/s against ~0.45 ms of kernel per M
     // reads), so what a schedule can take off the bracket is its END: the last chunk's kernel runs after the last copy
-    // with nothing beside it.  The tail is cut finer (kTail: 1/2, 1/4, 1/4 of a chunk by default; CAMMIQ_CHUNK_TAIL=0 for
-    // equal chunks), the head stays whole.
+    // with nothing beside it.  The tail is cut finer (1/2, 1/4, 1/4 of a chunk by default; CAMMIQ_CHUNK_TAIL=0 for equal
+    // chunks), and so is the head.
     std::vector<uint64_t> sched;
     {
         const int tail_on = getenv("CAMMIQ_CHUNK_TAIL") ? atoi(getenv("CAMMIQ_CHUNK_TAIL")) : 1;
         const uint64_t chunk = chunk_reads();
         uint64_t left = hi - lo;
         std::vector<uint64_t> tail;
-        if (tail_on && left >= 3 * chunk && !ascii) {
+        if (tail_on && left >= 4 * chunk && !ascii) {
+            // ... and the HEAD the other way round (1/4, 1/4, 1/2): the first kernel starts after a quarter of a chunk's copy
+            // instead of a whole one, which is what a board whose kernels, not the link, bound the bracket gets back
             tail = {chunk / 2, chunk / 4, chunk - chunk / 2 - chunk / 4};
-            left -= chunk;
+            left -= 2 * chunk;
+            sched = {chunk / 4, chunk / 4, chunk - 2 * (chunk / 4)};
         }
         while (left > 0) { const uint64_t n = std::min(chunk, left); sched.push_back(n); left -= n; }
         sched.insert(sched.end(), tail.begin(), tail.end());
@@ -1370,7 +1374,15 @@ int copy_out(cq_index *ix, void *dst, const void *d_src, size_t bytes)
     return CQ_OK;
 }
 
-// Device buffers, page-locked ring, events and worker threads of rcount's narrow way back, for nl leaves.
+// entries per segment of rcount's narrow way back (CAMMIQ_NARROW_SEG: test knob -- small segments take a small rcount
+// through many flags; a multiple of 64, read when a handle sets the path up)
+uint64_t narrow_seg()
+{
+    if (const char *v = getenv("CAMMIQ_NARROW_SEG")) return std::max<uint64_t>(64, strtoull(v, nullptr, 10) & ~63ull);
+    return cq::kNarrowSeg;
+}
+
+// Device buffers, page-locked landing area, flags and worker threads of rcount's narrow way back, for nl leaves.
 // CQ_OK with ix->pool == nullptr afterwards means "not available": the caller takes the plain copy.
 int ensure_narrow(cq_index *ix, uint64_t nl)
 {
@@ -1380,25 +1392,41 @@ int ensure_narrow(cq_index *ix, uint64_t nl)
         if (ix->pool) { ix->pool->stop(); delete ix->pool; ix->pool = nullptr; }
         return CQ_OK;
     }
-    if (ix->rc8_cap < nl) {
-        if (ix->d_rc8) (void)hipFree(ix->d_rc8);
-        ix->d_rc8 = nullptr; ix->rc8_cap = 0;
-        CQ_HIP(hipMalloc((void **)&ix->d_rc8, (nl + 15) / 16 * 16));
-        ix->rc8_cap = nl;
+    const uint64_t nseg = (nl + narrow_seg() - 1) / narrow_seg();
+    const bool timing = getenv("CAMMIQ_LOAD_TIMING") != nullptr;
+    auto t_n = std::chrono::steady_clock::now();
+    auto nlap = [&](const char *what) {
+        const auto now = std::chrono::steady_clock::now();
+        if (timing) fprintf(stderr, "[cq_index_load]     narrow: %-18s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_n).count());
+        t_n = now;
+    };
+    if (ix->narrow_cap < nl) {
+        if (ix->h_narrow) (void)hipHostFree(ix->h_narrow);
+        ix->h_narrow = nullptr; ix->narrow_cap = 0;
+        CQ_HIP(hipHostMalloc((void **)&ix->h_narrow, (nl + 63) / 64 * 64, hipHostMallocDefault));
+        ix->narrow_cap = nl;
+        nlap("pinned landing area");
+    }
+    if (ix->flags_cap < nseg + 1) {
+        if (ix->h_flags) (void)hipHostFree(ix->h_flags);
+        ix->h_flags = nullptr; ix->flags_cap = 0;
+        CQ_HIP(hipHostMalloc((void **)&ix->h_flags, (nseg + 1) * sizeof(uint32_t), hipHostMallocDefault));
+        memset(ix->h_flags, 0, (nseg + 1) * sizeof(uint32_t));
+        ix->flags_cap = nseg + 1;
+        ix->narrow_epoch = 0;
     }
     if (!ix->d_esc) {
         uint32_t cap = 1u << 20;                                       // 8 MB of (leaf, count) pairs
         if (const char *v = getenv("CAMMIQ_ESC_CAP")) cap = (uint32_t)std::max(1, atoi(v));   // test knob: force the fall-back
         CQ_HIP(hipMalloc((void **)&ix->d_esc, (size_t)cap * sizeof(uint2)));
         CQ_HIP(hipMalloc((void **)&ix->d_esc_count, sizeof(uint32_t)));
+        CQ_HIP(hipMalloc((void **)&ix->d_blocks_done, sizeof(uint32_t)));
+        CQ_HIP(hipMemset(ix->d_blocks_done, 0, sizeof(uint32_t)));
         CQ_HIP(hipHostMalloc((void **)&ix->h_esc, (size_t)cap * sizeof(uint2), hipHostMallocDefault));
         CQ_HIP(hipHostMalloc((void **)&ix->h_esc_count, sizeof(uint32_t), hipHostMallocDefault));
         ix->esc_cap = cap;
     }
-    if (!ix->h_ring) CQ_HIP(hipHostMalloc((void **)&ix->h_ring, (size_t)kNarrowRing * kNarrowPiece, hipHostMallocDefault));
-    for (auto &e : ix->ev_ring) if (!e) CQ_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     if (!ix->ev_narrow) CQ_HIP(hipEventCreateWithFlags(&ix->ev_narrow, hipEventDisableTiming));
-    if (!ix->s_d2h) CQ_HIP(hipStreamCreateWithFlags(&ix->s_d2h, hipStreamNonBlocking));
     if (ix->pool && ix->pool->th.size() != widen_threads()) { ix->pool->stop(); delete ix->pool; ix->pool = nullptr; }   // knob changed
     if (!ix->pool) {
         WidenPool *p = new (std::nothrow) WidenPool();
@@ -1406,16 +1434,17 @@ int ensure_narrow(cq_index *ix, uint64_t nl)
         try { p->start(widen_threads()); } catch (...) { p->stop(); delete p; return CQ_OK; }   // no threads to be had: plain copy
         ix->pool = p;
     }
+    nlap("flags, escapes, pool");
     return CQ_OK;
 }
 
 // rcount (ix->d_rc, nl = n_u + n_d leaves) -> the caller's two uint32 arrays, narrow over the link:
-//   device   narrow_rcount_kernel: uint32 -> one byte per leaf (saturated at 255) + escape list        (~0.1 ms / 84 M leaves)
-//   link     the bytes in kNarrowPiece pieces into a page-locked ring                                   (a quarter of the bytes)
-//   host     the pool's threads widen piece k into rcount_u / rcount_d while piece k+1.. arrive; the
-//            escaped entries are written last.
-// Bit-exact with the plain copy (tests: a leaf forced past 255, the escape list overrun -> *fell_back = true and nothing
-// written).  What a query hands the ILP is unchanged: uint32 per leaf in decode order (query.cpp:1161,1176-1177).
+//   device + link   narrow_rcount_kernel: uint32 -> one byte per leaf (saturated at 255) + escape list; the kernel's lanes
+//                   write the bytes straight into page-locked host memory and flag every finished segment
+//   host            the pool's threads poll the flags and widen segment after segment into rcount_u / rcount_d (streaming
+//                   stores); the escaped entries are written last.
+// Bit-exact with the plain copy (tests: leaves forced past 255, the escape list overrun -> *fell_back = true, plain copy).
+// What a query hands the ILP is unchanged: uint32 per leaf in decode order (query.cpp:1161,1176-1177).
 int fetch_rcount_narrow(cq_index *ix, uint64_t n_u, uint64_t n_d, uint32_t *dst_u, uint32_t *dst_d, bool *fell_back)
 {
     const uint64_t nl = n_u + n_d;
@@ -1426,53 +1455,44 @@ int fetch_rcount_narrow(cq_index *ix, uint64_t n_u, uint64_t n_d, uint32_t *dst_
     WidenPool &P = *ix->pool;
     const unsigned W = (unsigned)P.th.size();
     PipeTrace *tr = ix->trace;
+    const uint64_t seg = narrow_seg(), nseg = (nl + seg - 1) / seg;
+    if (ix->flags_cap < nseg + 1) return fail(CQ_ERR_ARG, "narrow rcount: segment size changed under a live handle");
+    if (++ix->narrow_epoch == 0) {   // the epoch wrapped (2^32 queries): start the flags over
+        memset(ix->h_flags, 0, ix->flags_cap * sizeof(uint32_t));
+        ix->narrow_epoch = 1;
+    }
+    const uint32_t epoch = ix->narrow_epoch;
     CQ_HIP(hipMemsetAsync(ix->d_esc_count, 0, sizeof(uint32_t), ix->s_comp));
     if (tr) tr->dev("narrow_begin", 0, ix->s_comp);
-    CQ_HIP(cq::launch_narrow_rcount(ix->d_rc, nl, ix->d_rc8, ix->d_esc, ix->d_esc_count, ix->esc_cap, ix->s_comp));
+    CQ_HIP(cq::launch_narrow_rcount(ix->d_rc, nl, ix->h_narrow, seg, ix->h_flags, epoch, ix->d_esc, ix->d_esc_count, ix->esc_cap, ix->d_blocks_done,
+                                    ix->h_esc_count, ix->s_comp));
     CQ_HIP(hipEventRecord(ix->ev_narrow, ix->s_comp));
     if (tr) tr->dev("narrow_end", 0, ix->s_comp);
-    // the pieces (and the count of escapes in front of them) come back on a queue of their own (CAMMIQ_D2H_ON_COPY=1: the
-    // rows' copy queue, as the first version of this path did -- A/B knob)
-    hipStream_t s_back = (getenv("CAMMIQ_D2H_ON_COPY") && atoi(getenv("CAMMIQ_D2H_ON_COPY"))) ? ix->s_copy : ix->s_d2h;
-    CQ_HIP(hipStreamWaitEvent(s_back, ix->ev_narrow, 0));
-    hipStream_t s_small = s_back;
-    CQ_HIP(hipMemcpyAsync(ix->h_esc_count, ix->d_esc_count, sizeof(uint32_t), hipMemcpyDeviceToHost, s_small));
-    uint64_t piece = kNarrowPiece;
-    if (const char *v = getenv("CAMMIQ_NARROW_PIECE"))   // test knob: small pieces take a small rcount through the whole ring
-        piece = std::min<uint64_t>(kNarrowPiece, std::max<uint64_t>(64, strtoull(v, nullptr, 10) & ~63ull));
-    const uint64_t np = (nl + piece - 1) / piece;
-    auto piece_bytes = [&](uint64_t k) { return (size_t)std::min<uint64_t>(piece, nl - k * piece); };
-    auto enqueue = [&](uint64_t k) -> hipError_t {
-        hipError_t e = hipMemcpyAsync(ix->h_ring + (k % kNarrowRing) * piece, ix->d_rc8 + k * piece, piece_bytes(k),
-                                      hipMemcpyDeviceToHost, s_back);
-        return e != hipSuccess ? e : hipEventRecord(ix->ev_ring[k % kNarrowRing], s_back);
-    };
-    for (uint64_t k = 0; k < np && k < (uint64_t)kNarrowRing; k++) CQ_HIP(enqueue(k));
-    {   // wake the workers: they spin on `ready` from here on
+    {   // wake the workers: they poll the flags from here on
         std::lock_guard<std::mutex> lk(P.mu);
-        P.ring = ix->h_ring; P.n = nl; P.n_u = n_u; P.n_pieces = np; P.piece = piece; P.dst_u = dst_u; P.dst_d = dst_d;
-        P.ready.store(0); P.workers_done.store(0);
-        for (auto &f : P.fin) f.store(0);
+        P.narrow = ix->h_narrow; P.flags = ix->h_flags; P.epoch = epoch; P.n = nl; P.n_u = n_u; P.n_segments = nseg; P.seg = seg;
+        P.dst_u = dst_u; P.dst_d = dst_d;
+        P.next.store(0); P.workers_done.store(0); P.abort.store(false);
         P.job_seq++;
     }
     P.cv.notify_all();
+    // the kernel's completion is watched too: if it failed no flag will ever come
     hipError_t bad = hipSuccess;
-    for (uint64_t k = 0; k < np; k++) {
-        if (bad == hipSuccess) bad = hipEventSynchronize(ix->ev_ring[k % kNarrowRing]);
-        P.ready.store(k + 1, std::memory_order_release);                // (after a failed copy the workers widen garbage; the error is returned below)
-        if (k + kNarrowRing < np) {
-            // slot k % ring is free again once every worker is through with piece k
-            const uint64_t want = (uint64_t)W * (k / kNarrowRing + 1);
-            while (P.fin[k % kNarrowRing].load(std::memory_order_acquire) < want) _mm_pause();
-            if (bad == hipSuccess) bad = enqueue(k + kNarrowRing);
+    const volatile uint32_t *flags = ix->h_flags;
+    uint64_t spins = 0;
+    while (P.workers_done.load(std::memory_order_acquire) < W) {
+        _mm_pause();
+        if ((++spins & 0xFFFF) == 0 && flags[nseg] != epoch) {
+            const hipError_t q = hipEventQuery(ix->ev_narrow);
+            if (q != hipSuccess && q != hipErrorNotReady) { bad = q; P.abort.store(true); }
         }
     }
-    if (tr) { tr->dev("d2h_last_piece", (int)np, s_back); tr->host("pieces_copied", (int)np); }
-    while (P.workers_done.load(std::memory_order_acquire) < W) _mm_pause();
-    if (tr) tr->host("widened", (int)np);
-    if (bad != hipSuccess) return fail(CQ_ERR_HIP, std::string("narrow rcount copy: ") + hipGetErrorString(bad));
-    CQ_HIP(hipStreamSynchronize(s_small));
-    const uint32_t n_esc = *ix->h_esc_count;
+    if (tr) tr->host("widened", (int)nseg);
+    if (bad != hipSuccess) return fail(CQ_ERR_HIP, std::string("narrow rcount kernel: ") + hipGetErrorString(bad));
+    CQ_HIP(hipEventSynchronize(ix->ev_narrow));
+    if (flags[nseg] != epoch) return fail(CQ_ERR_HIP, "narrow rcount kernel ended without its final flag");
+    std::atomic_thread_fence(std::memory_order_acquire);
+    const uint32_t n_esc = *(volatile uint32_t *)ix->h_esc_count;
     if (n_esc > ix->esc_cap) return CQ_OK;                               // more saturated leaves than the list holds: plain copy (fell_back stays true)
     if (n_esc) {
         CQ_HIP(hipMemcpy(ix->h_esc, ix->d_esc, (size_t)n_esc * sizeof(uint2), hipMemcpyDeviceToHost));

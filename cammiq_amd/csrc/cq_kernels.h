@@ -71,11 +71,14 @@ hipError_t launch_accumulate(uint64_t *dst64, const uint64_t *src64, uint64_t n6
 hipError_t launch_widen_rows(const uint8_t *tight, uint32_t sb, uint32_t *rows, uint32_t sw, uint64_t n_reads,
                              hipStream_t stream);
 
-// rcount (uint32 per leaf, device) -> one byte per leaf saturated at 255 + an escape list of (leaf, count) for the
-// entries of 255 and more (*esc_count counts them all, esc holds the first esc_cap): the narrow form rcount crosses
-// the link in (cq_api.cpp fetch_counts).  rc must be 16-byte aligned.
-hipError_t launch_narrow_rcount(const uint32_t *rc, uint64_t n, uint8_t *out8, uint2 *esc, uint32_t *esc_count, uint32_t esc_cap,
-                                hipStream_t stream);
+// rcount (uint32 per leaf, device) -> one byte per leaf saturated at 255, WRITTEN BY THE KERNEL INTO PAGE-LOCKED HOST
+// MEMORY (host_out8: n bytes), + an escape list of (leaf, count) for the entries of 255 and more (device; *esc_count counts
+// them all, esc holds the first esc_cap).  host_flags[s] = epoch once segment s (kNarrowSeg entries) is on the host;
+// host_flags[n_segments] = epoch and *host_esc_count = the number of escapes once all of them are.  blocks_done: a device
+// word, zero between calls.  rc must be 16-byte aligned (cq_api.cpp fetch_rcount_narrow).
+constexpr uint64_t kNarrowSeg = 1ull << 18;
+hipError_t launch_narrow_rcount(const uint32_t *rc, uint64_t n, uint8_t *host_out8, uint64_t seg, uint32_t *host_flags, uint32_t epoch, uint2 *esc,
+                                uint32_t *esc_count, uint32_t esc_cap, uint32_t *blocks_done, uint32_t *host_esc_count, hipStream_t stream);
 
 // Board calibrators behind cq_calibrate (diagnostic): `grid` workgroups of 256 lanes, each lane `iters` random 16-byte
 // loads from tab[0 .. n_units); mix = with a returnless atomic into atom[0 .. n_atom) per 16 loads and LDS traffic
@@ -83,7 +86,7 @@ hipError_t launch_narrow_rcount(const uint32_t *rc, uint64_t n, uint8_t *out8, u
 hipError_t launch_calib_gather(bool mix, const uint4 *tab, uint64_t n_units, int iters, uint32_t *atom, uint64_t n_atom,
                                uint64_t *stamps, uint32_t *sink, int grid, hipStream_t stream);
 
-// ... and the latency calibrator: every lane `iters` DEPENDENT random 16-byte loads (one in flight per lane).
+// ... and the latency calibrator: `grid` single waves, every lane `iters` DEPENDENT random 16-byte loads (one in flight per lane).
 hipError_t launch_calib_chase(const uint4 *tab, uint64_t n_units, int iters, uint64_t *stamps, uint32_t *sink, int grid, hipStream_t stream);
 
 }  // namespace cq

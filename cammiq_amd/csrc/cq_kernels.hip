@@ -900,40 +900,62 @@ hipError_t launch_widen_rows(const uint8_t *tight, uint32_t sb, uint32_t *rows, 
 // rcount leaves the device NARROW: one byte per leaf (the count, saturated at 255) plus an escape list of
 // (leaf, count) for the few entries of 255 and more; the host widens into the caller's uint32 arrays
 // (pleafNode::rcount is a uint32, hashtrie.hpp:43) and overwrites the escaped entries -- bit-exact, a quarter of
-// the bytes on the link behind the last classify kernel.  A thread takes 16 consecutive entries: four 16-byte
-// loads, one 16-byte store.  *esc_count may end above esc_cap: the host then falls back to the plain uint32 copy.
+// the bytes on the link behind the last classify kernel.
+//
+// The kernel IS the copy: out8 and flags are page-locked HOST memory, written by the lanes themselves (16 entries per lane
+// and step: four 16-byte loads from HBM, one 16-byte store over the link; a wave's store is 1 KB contiguous).  A workgroup
+// owns one segment of `seg` entries (kNarrowSeg); when its bytes are out it publishes flags[segment] = epoch (system-scope
+// release), which the host's widening threads poll -- no event, no runtime call, no wake-up between the link and the
+// threads (the first version copied pieces with hipMemcpyAsync + one hipEventSynchronize per piece: the hand-offs, not the
+// bytes, made a 1.5 ms transfer take 4.4 ms).  The workgroup that finishes last publishes the number of escapes and the
+// final flag flags[n_segments].  *esc_count may end above esc_cap: the host then falls back to the plain uint32 copy.
 __global__ void __launch_bounds__(256) narrow_rcount_kernel(const uint32_t *__restrict__ rc, uint64_t n, uint8_t *__restrict__ out8,
-                                                            uint2 *__restrict__ esc, uint32_t *__restrict__ esc_count, uint32_t esc_cap)
+                                                            uint64_t seg, uint32_t *__restrict__ flags, uint32_t epoch, uint2 *__restrict__ esc,
+                                                            uint32_t *__restrict__ esc_count, uint32_t esc_cap, uint32_t *__restrict__ blocks_done,
+                                                            uint32_t *__restrict__ host_esc_count)
 {
-    const uint64_t n16 = n / 16, stride = (uint64_t)gridDim.x * blockDim.x, tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     auto squeeze = [&](uint32_t v, uint64_t idx) -> uint32_t {
         if (v < 255u) return v;
         const uint32_t at = atomicAdd(esc_count, 1u);
         if (at < esc_cap) esc[at] = make_uint2((uint32_t)idx, v);
         return 255u;
     };
-    for (uint64_t g = tid; g < n16; g += stride) {
-        const uint4 *src = (const uint4 *)(rc + g * 16);
+    const uint64_t lo = (uint64_t)blockIdx.x * seg, hi = lo + seg < n ? lo + seg : n;   // seg is a multiple of 16: lo stays 16-entry aligned
+    const uint64_t hi16 = lo + ((hi - lo) & ~(uint64_t)15);
+    for (uint64_t i = lo + (uint64_t)threadIdx.x * 16; i < hi16; i += 256 * 16) {
+        const uint4 *src = (const uint4 *)(rc + i);
         uint32_t w[4];
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const uint4 v = src[q];
-            const uint64_t i0 = g * 16 + (uint64_t)q * 4;
+            const uint64_t i0 = i + (uint64_t)q * 4;
             w[q] = squeeze(v.x, i0) | squeeze(v.y, i0 + 1) << 8 | squeeze(v.z, i0 + 2) << 16 | squeeze(v.w, i0 + 3) << 24;
         }
-        ((uint4 *)out8)[g] = make_uint4(w[0], w[1], w[2], w[3]);
+        *(uint4 *)(out8 + i) = make_uint4(w[0], w[1], w[2], w[3]);
     }
-    for (uint64_t i = n16 * 16 + tid; i < n; i += stride) out8[i] = (uint8_t)squeeze(rc[i], i);
+    for (uint64_t i = hi16 + threadIdx.x; i < hi; i += 256) out8[i] = (uint8_t)squeeze(rc[i], i);
+    __threadfence_system();   // this lane's bytes are on the host before the flag can be
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(flags + blockIdx.x, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (atomicAdd(blocks_done, 1u) == gridDim.x - 1) {   // every other workgroup's escapes are counted (their atomics precede their ticket)
+            __threadfence();
+            *host_esc_count = __hip_atomic_load(esc_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *blocks_done = 0;
+            __threadfence_system();
+            __hip_atomic_store(flags + gridDim.x, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
 }
 
-hipError_t launch_narrow_rcount(const uint32_t *rc, uint64_t n, uint8_t *out8, uint2 *esc, uint32_t *esc_count, uint32_t esc_cap,
-                                hipStream_t stream)
+hipError_t launch_narrow_rcount(const uint32_t *rc, uint64_t n, uint8_t *host_out8, uint64_t seg, uint32_t *host_flags, uint32_t epoch, uint2 *esc,
+                                uint32_t *esc_count, uint32_t esc_cap, uint32_t *blocks_done, uint32_t *host_esc_count, hipStream_t stream)
 {
     if (n == 0) return hipSuccess;
-    uint64_t grid = (n / 16 + 255) / 256;
-    if (grid < 1) grid = 1;
-    if (grid > 256 * 16) grid = 256 * 16;
-    hipLaunchKernelGGL(narrow_rcount_kernel, dim3((unsigned)grid), dim3(256), 0, stream, rc, n, out8, esc, esc_count, esc_cap);
+    if (seg == 0 || (seg & 15u)) return hipErrorInvalidValue;
+    const uint64_t grid = (n + seg - 1) / seg;
+    hipLaunchKernelGGL(narrow_rcount_kernel, dim3((unsigned)grid), dim3(256), 0, stream, rc, n, host_out8, seg, host_flags, epoch, esc, esc_count, esc_cap,
+                       blocks_done, host_esc_count);
     return hipGetLastError();
 }
 
@@ -987,7 +1009,9 @@ __global__ void __launch_bounds__(256) calib_gather_kernel(const uint4 *__restri
 }
 
 // The third calibrator: DEPENDENT random loads -- the address of a lane's next 16-byte load is a function of the quad
-// the last one returned (one load in flight per lane) -- at the classify kernel's residency.  The classify kernel is a
+// the last one returned (one load in flight per lane) -- from ONE wave per CU (at the classify kernel's residency the
+// chase saturates the memory system like the gather does: 40 G loads/s either way; one wave per CU is far below that,
+// so lanes in flight / rate is what a lone request takes).  The classify kernel is a
 // chain of such round trips per sub-tile (bucket quad -> compare -> bucket re-read -> trie node -> refIDs) hidden only
 // by the number of resident waves, so what a board's memory system answers a lone request in decides its time where the
 // saturated gather rate above is the same on every board.  rate = loads/s; latency = lanes in flight / rate.
@@ -1011,7 +1035,7 @@ __global__ void __launch_bounds__(256) calib_chase_kernel(const uint4 *__restric
 
 hipError_t launch_calib_chase(const uint4 *tab, uint64_t n_units, int iters, uint64_t *stamps, uint32_t *sink, int grid, hipStream_t stream)
 {
-    hipLaunchKernelGGL(calib_chase_kernel, dim3((unsigned)grid), dim3(256), 0, stream, tab, n_units, iters, stamps, sink);
+    hipLaunchKernelGGL(calib_chase_kernel, dim3((unsigned)grid), dim3(64), 0, stream, tab, n_units, iters, stamps, sink);
     return hipGetLastError();
 }
 

@@ -354,12 +354,15 @@ hipError_t layout_table_on_device(const uint64_t *d_keys, const uint32_t *d_vals
         LG((device_scan<OpSum, false>(cnt, start, n_buckets, &total, st)));
         if ((uint64_t)total != n) { e = hipErrorUnknown; goto done; }
         // 3. scatter into home groups
+        tm.lap("  scan (group starts)");
         LG(hipMalloc((void **)&rec, std::max<uint64_t>(n, 1) * sizeof(Rec)));
+        tm.lap("  hipMalloc (records)");
         if (n) hipLaunchKernelGGL(scatter_kernel, dim3(grid_for(n, n_cus)), dim3(kBlock), 0, st, d_keys, home, n, start, cnt, rec);
         LG(hipGetLastError());
         LG(hipStreamSynchronize(st));
+        tm.lap("  scatter");
         (void)hipFree(home); home = nullptr;
-        tm.lap("scan + scatter");
+        tm.lap("  hipFree (homes)");
         // 4. sort + merge inside every home group; cnt becomes the distinct-key count of the group
         LG(hipMalloc((void **)&too_big, 4));
         LG(hipMemsetAsync(too_big, 0, 4, st));
@@ -375,17 +378,20 @@ hipError_t layout_table_on_device(const uint64_t *d_keys, const uint32_t *d_vals
         LG((device_scan<OpSum, false>(cnt, ustart, n_buckets, &n_keys, st)));
         out.n_keys = n_keys;
         // 6. compact + the sweep's scan input
+        tm.lap("  scan (ranks)");
         LG(hipMalloc((void **)&E, std::max<uint64_t>(n_keys, 1) * sizeof(Rec)));
         LG(hipMalloc((void **)&hj, std::max<uint64_t>(n_keys, 1) * 4));
         LG(hipMalloc((void **)&g, std::max<uint64_t>(n_keys, 1) * 8));
+        tm.lap("  hipMalloc (ranked keys)");
         hipLaunchKernelGGL(compact_kernel, dim3(grid_for(n_buckets, n_cus)), dim3(kBlock), 0, st, rec, start, cnt, ustart, n_buckets, E, hj, g);
         LG(hipGetLastError());
         LG(hipStreamSynchronize(st));
+        tm.lap("rank + compact");
         (void)hipFree(rec); rec = nullptr;
         (void)hipFree(start); start = nullptr;
         (void)hipFree(ustart); ustart = nullptr;
         (void)hipFree(cnt); cnt = nullptr;
-        tm.lap("rank + compact");
+        tm.lap("  hipFree (records, counts)");
         // 7. the placement sweep: s_j = j + max_{i <= j} (4 home_i - i)
         long long gmax = 0;
         LG((device_scan<OpMax, true>(g, g, n_keys, &gmax, st)));

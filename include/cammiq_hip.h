@@ -290,8 +290,8 @@ int cq_last_launch_info(cq_index *idx, cq_launch_info *out);
  *   gather16_mix_Glines_s  the same loads with a returnless global atomic per 16 loads into an rcount-sized array and
  *                          LDS stores / reads beside them (what the real kernel has and a plain gather lacks)
  *   chase16_Glines_s       DEPENDENT random 16-byte loads per second (one in flight per lane: the next address is a
- *                          function of the loaded quad) at 6 workgroups of 256 lanes per CU, the classify kernel's
- *                          residency; chase_latency_ns = lanes in flight / that rate -- what the memory system answers
+ *                          function of the loaded quad) from ONE wave per CU -- far below what saturates the memory
+ *                          system; chase_latency_ns = lanes in flight / that rate -- what the memory system answers
  *                          a lone request in, which a latency-hiding kernel follows and a saturated gather does not show
  *   clock_MHz_*            shader clock held DURING each of the kernels: shader cycles / 100 MHz constant-clock
  *                          ticks (s_memtime / s_memrealtime), median over workgroups

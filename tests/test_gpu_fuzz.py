@@ -23,7 +23,7 @@ pytestmark = pytest.mark.gpu
 
 _KNOBS = ("CAMMIQ_MAX_SUB_PER_WAVE", "CAMMIQ_LDS_HIST_MAX", "CAMMIQ_KEYS_PER_BUCKET", "CAMMIQ_BLOCKS_PER_CU",
           "CAMMIQ_PAIR_SLOTS", "CAMMIQ_FAST_R", "CAMMIQ_MINIMIZER_LEN", "CAMMIQ_NO_FIXED_SHAPE", "CAMMIQ_GPU_LAYOUT",
-          "CAMMIQ_NARROW_FROM", "CAMMIQ_NARROW_PIECE")
+          "CAMMIQ_NARROW_FROM", "CAMMIQ_NARROW_SEG")
 
 
 def _draw(seed):
@@ -67,7 +67,7 @@ def _draw(seed):
     w["env"]["CAMMIQ_GPU_LAYOUT"] = r.choice(["verify", "verify", "1", "0"])
     if r.random() < 0.5:
         w["env"]["CAMMIQ_NARROW_FROM"] = "1"
-        w["env"]["CAMMIQ_NARROW_PIECE"] = r.choice(["64", "1024", "65536"])
+        w["env"]["CAMMIQ_NARROW_SEG"] = r.choice(["64", "1024", "65536"])
     return w
 
 
@@ -177,7 +177,7 @@ def _draw_generator(seed):
     w["env"]["CAMMIQ_GPU_LAYOUT"] = r.choice(["verify", "verify", "1", "0"])    # round 4, drawn last: see _draw
     if r.random() < 0.5:
         w["env"]["CAMMIQ_NARROW_FROM"] = "1"
-        w["env"]["CAMMIQ_NARROW_PIECE"] = r.choice(["64", "4096", "65536"])
+        w["env"]["CAMMIQ_NARROW_SEG"] = r.choice(["64", "4096", "65536"])
     return w
 
 

@@ -153,8 +153,8 @@ def test_large_rcount_comes_back_through_the_bounce_buffers(tmp_path):
 def test_rcount_comes_back_narrow_and_exact(tmp_path, monkeypatch, how):
     """rcount crosses the link as one byte per leaf + an escape list for counts of 255 and more and is widened into the
     caller's uint32 arrays by the library (cq_api.cpp fetch_rcount_narrow): bit-exact with the oracle with leaves forced far
-    past 255 (every read of a block repeated 700 times), through a ring of small pieces (each ring slot reused many
-    times, pieces that straddle the u / d boundary), into pinned and into pageable arrays, for every host-fed door; when
+    past 255 (every read of a block repeated 700 times), through many small segments (each written to page-locked host memory and flagged by its own
+    workgroup, one straddling the u / d boundary), into pinned and into pageable arrays, for every host-fed door; when
     the escape list overruns (forced: 3 entries) the plain uint32 copy takes over, silently and exactly."""
     from cammiq_amd import bigsynth
     G = 40
@@ -172,8 +172,8 @@ def test_rcount_comes_back_narrow_and_exact(tmp_path, monkeypatch, how):
     assert int((ref["rcount_u"] >= 255).sum() + (ref["rcount_d"] >= 255).sum()) > 3
     monkeypatch.setenv("CAMMIQ_NARROW_FROM", "1")
     if how == "ring":
-        monkeypatch.setenv("CAMMIQ_NARROW_PIECE", "4096")       # (nu + nd) / 4096 pieces through the 8 ring slots
-        assert (nu + nd) // 4096 > 24 and nu % 4096 != 0
+        monkeypatch.setenv("CAMMIQ_NARROW_SEG", "4096")       # (nu + nd) / 4096 segments, each flagged by its workgroup
+        assert (nu + nd) // 4096 > 24 and nu % 4096 != 0         # ... and one of them straddles the u / d boundary
     elif how == "escapes_overrun":
         monkeypatch.setenv("CAMMIQ_ESC_CAP", "3")
     else:

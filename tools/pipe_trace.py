@@ -28,8 +28,8 @@ def summarise(path):
         print(f"widen per chunk median {med(wd):.3f} ms; kernel begins {med(lag):.3f} ms (median) after its chunk's copy ended, max {max(lag):.3f}")
     if "narrow_begin" in dev:
         nb, ne = dev["narrow_begin"][0], dev["narrow_end"][0]
-        lp = list(dev["d2h_last_piece"].values())[0]
-        print(f"tail: last kernel ends +{dev['kernel_end'][nch - 1]:.3f}; narrow kernel +{nb:.3f} .. +{ne:.3f}; last rcount piece on the host +{lp:.3f}")
+        print(f"tail: last kernel ends +{dev['kernel_end'][nch - 1]:.3f}; narrow kernel (its lanes write rcount's bytes into page-locked host memory) "
+              f"+{nb:.3f} .. +{ne:.3f} ({ne - nb:.3f} ms)")
     h0 = host.get("slot_wait", {}).get(0, 0.0)
     for k in ("kernels_done", "pieces_copied", "widened", "query_done"):
         if k in host:
