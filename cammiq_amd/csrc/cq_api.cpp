@@ -274,8 +274,12 @@ struct cq_index {
         uint8_t *d_tight = nullptr;                          // tight rows as they arrive (cq_query_packed_tight), widened into d_packed
         size_t cap_words_h = 0, cap_reads_h = 0, cap_words_d = 0, cap_reads_d = 0, cap_tight = 0;
         hipEvent_t copied = nullptr, copied_lens = nullptr, widened = nullptr, done = nullptr;
+        uint32_t *d_ovf_list = nullptr, *d_ovf_count = nullptr;   // this slot's slow-path list: the kernels of consecutive chunks overlap
+        uint64_t ovf_cap = 0;
     } slot[kSlots];   // the host may enqueue the copies of the next chunks while the kernels of the chunks before are still running
     hipStream_t s_copy = nullptr, s_copy2 = nullptr, s_comp = nullptr;   // rows | lengths (their own DMA queue) | kernels
+    hipStream_t s_comp2 = nullptr;   // the kernels of odd chunks: chunk c + 1 fills the CUs while chunk c drains
+    hipEvent_t ev_zeroed = nullptr, ev_comp2 = nullptr;
     hipStream_t s_widen = nullptr;   // tight rows -> word rows, beside the classify kernel of the chunk before (it leaves wave slots free)
     uint64_t *d_ctr = nullptr; size_t ctr_cap = 0;
     uint32_t *d_rc = nullptr; size_t rc_cap = 0;
@@ -291,6 +295,8 @@ struct cq_index {
     uint2 *h_esc = nullptr; uint32_t *h_esc_count = nullptr;
     hipEvent_t ev_narrow = nullptr;
     WidenPool *pool = nullptr;
+    bool narrow_inflight = false;              // narrow_start has queued the kernel and woken the pool; narrow_finish collects
+    uint64_t narrow_nseg = 0;
     PipeTrace *trace = nullptr;                // CAMMIQ_PIPE_TRACE: the query being traced (classify_range .. fetch_counts)
 };
 
@@ -348,7 +354,12 @@ void release_device(cq_index *ix)
         if (sl.copied_lens) (void)hipEventDestroy(sl.copied_lens);
         if (sl.widened) (void)hipEventDestroy(sl.widened);
         if (sl.done) (void)hipEventDestroy(sl.done);
+        if (sl.d_ovf_list) (void)hipFree(sl.d_ovf_list);
+        if (sl.d_ovf_count) (void)hipFree(sl.d_ovf_count);
     }
+    if (ix->s_comp2) (void)hipStreamDestroy(ix->s_comp2);
+    if (ix->ev_zeroed) (void)hipEventDestroy(ix->ev_zeroed);
+    if (ix->ev_comp2) (void)hipEventDestroy(ix->ev_comp2);
     for (void *b : ix->h_bounce) if (b) (void)hipHostFree(b);
     if (ix->s_copy) (void)hipStreamDestroy(ix->s_copy);
     if (ix->s_copy2) (void)hipStreamDestroy(ix->s_copy2);
@@ -825,11 +836,33 @@ void cq_host_free(void *p)
     if (p) (void)hipHostFree(p);
 }
 
+}  // extern "C"
+
+namespace {
+// The slow-path list a launch hands its over-full reads to: the handle's own (cq_query_device: one launch after the
+// other on the caller's stream), or a staging slot's (host-fed pipeline: the kernels of consecutive chunks overlap).
+struct OvfRef { uint32_t **list; uint32_t **count; uint64_t *cap; };
+int query_device_impl(cq_index *ix, int mode, const uint32_t *d_packed, const uint8_t *d_lens, uint64_t n_reads, uint32_t stride_words,
+                      uint32_t max_len, uint32_t n_genomes, uint64_t *d_counters, uint32_t *d_rcount, hipStream_t st, OvfRef ovf);
+}  // namespace
+
+extern "C" {
+
 int cq_query_device(cq_index *ix, int mode, const uint32_t *d_packed, const uint8_t *d_lens,
                     uint64_t n_reads, uint32_t stride_words, uint32_t max_len, uint32_t n_genomes,
                     uint64_t *d_counters, uint32_t *d_rcount, void *stream)
 {
     if (!ix) return fail(CQ_ERR_ARG, "cq_query_device: NULL handle");
+    return query_device_impl(ix, mode, d_packed, d_lens, n_reads, stride_words, max_len, n_genomes, d_counters, d_rcount, (hipStream_t)stream,
+                             OvfRef{&ix->d_ovf_list, &ix->d_ovf_count, &ix->ovf_cap});
+}
+
+}  // extern "C"
+
+namespace {
+int query_device_impl(cq_index *ix, int mode, const uint32_t *d_packed, const uint8_t *d_lens, uint64_t n_reads, uint32_t stride_words,
+                      uint32_t max_len, uint32_t n_genomes, uint64_t *d_counters, uint32_t *d_rcount, hipStream_t st, OvfRef ovf)
+{
     if (ix->device < 0) return fail(CQ_ERR_NO_DEVICE, "index was loaded host-only (CQ_DEVICE_NONE); no CPU classify path exists");
     if (mode != CQ_MODE_P && mode != CQ_MODE_SC) return fail(CQ_ERR_ARG, "cq_query_device: unknown mode");
     if (!d_counters || (n_reads && (!d_packed || !d_lens)) || stride_words == 0 || stride_words > 16)
@@ -839,16 +872,16 @@ int cq_query_device(cq_index *ix, int mode, const uint32_t *d_packed, const uint
     if (img.max_refid > n_genomes)
         return fail(CQ_ERR_RANGE, "index holds refID " + std::to_string(img.max_refid) + " > n_genomes");
     if (n_reads == 0) return CQ_OK;
-    hipStream_t st = (hipStream_t)stream;
     CQ_HIP(hipSetDevice(ix->device));
-    if (ix->ovf_cap < n_reads) {   // grow the slow-path list (outside steady state)
+    if (!*ovf.count) CQ_HIP(hipMalloc((void **)ovf.count, sizeof(uint32_t)));
+    if (*ovf.cap < n_reads) {   // grow the slow-path list (outside steady state)
         CQ_HIP(hipDeviceSynchronize());   // an earlier launch may still be using the old list
-        if (ix->d_ovf_list) CQ_HIP(hipFree(ix->d_ovf_list));
-        ix->d_ovf_list = nullptr;
-        CQ_HIP(hipMalloc((void **)&ix->d_ovf_list, n_reads * sizeof(uint32_t)));
-        ix->ovf_cap = n_reads;
+        if (*ovf.list) CQ_HIP(hipFree(*ovf.list));
+        *ovf.list = nullptr;
+        CQ_HIP(hipMalloc((void **)ovf.list, n_reads * sizeof(uint32_t)));
+        *ovf.cap = n_reads;
     }
-    CQ_HIP(hipMemsetAsync(ix->d_ovf_count, 0, sizeof(uint32_t), st));
+    CQ_HIP(hipMemsetAsync(*ovf.count, 0, sizeof(uint32_t), st));
     const uint32_t h = img.hash_len;
     if (max_len == 0 || max_len > stride_words * 16) max_len = stride_words * 16;
     if (max_len > 255) max_len = 255;
@@ -862,9 +895,9 @@ int cq_query_device(cq_index *ix, int mode, const uint32_t *d_packed, const uint
     a.mode = mode;
     a.counters = d_counters;
     a.rcount = (mode == CQ_MODE_P) ? d_rcount : nullptr;
-    a.ovf_list = ix->d_ovf_list;
-    a.ovf_count = ix->d_ovf_count;
-    a.ovf_cap = (uint32_t)ix->ovf_cap;
+    a.ovf_list = *ovf.list;
+    a.ovf_count = *ovf.count;
+    a.ovf_cap = (uint32_t)*ovf.cap;
     a.pair_keys = ix->d_pair_keys;
     a.pair_cnts = ix->d_pair_cnts;
     a.pair_cap = ix->pair_cap;
@@ -873,6 +906,9 @@ int cq_query_device(cq_index *ix, int mode, const uint32_t *d_packed, const uint
     ix->ev_valid = true;
     return CQ_OK;
 }
+}  // namespace
+
+extern "C" {
 
 int cq_last_launch_info(cq_index *ix, cq_launch_info *out)
 {
@@ -1157,20 +1193,28 @@ int query_checks(const cq_index *ix, int mode, uint32_t n_genomes, const cq_coun
     return CQ_OK;
 }
 
+int narrow_start(cq_index *ix, uint64_t n_u, uint64_t n_d, uint32_t *dst_u, uint32_t *dst_d);   // below (rcount's narrow way back)
+
 // Classify reads [lo, hi) of `f` on ix's device into the handle's own counter block (d_ctr) and
 // rcount array (d_rc), both zeroed first: resetCounters + query64_* (query.cpp:1820-1840, 458-1080).
-// Chunks of 2 M reads rotate over three staging slots:
-//   CPU   pack(c+1) ........ pack(c+2) ........          (ASCII feed only)
-//   copy           H2D(c+1) ...........H2D(c+2)
-//   comp  kernel(c) ........ kernel(c+1) .......
-// Returns with everything complete on the device (s_comp synchronised).
-int classify_range(cq_index *ix, int mode, const Feed &f, uint64_t lo, uint64_t hi, uint32_t n_genomes)
+// Chunks of 2 M reads rotate over four staging slots:
+//   CPU    pack(c+1) ........ pack(c+2) ........          (ASCII feed only)
+//   copy            H2D(c+1) ...........H2D(c+2)
+//   comp   kernel(c) ........          kernel(c+2) ......     even chunks
+//   comp2            kernel(c+1) ........                      odd chunks: c + 1 fills the CUs while c drains
+// out != nullptr (one device, CQ_MODE_P): rcount's narrow way back is started behind the last kernel BEFORE the host
+// waits for the kernels (narrow_start), so no host round trip sits between the two; fetch_counts finishes it.
+// Returns with every classify kernel complete on the device.
+int classify_range(cq_index *ix, int mode, const Feed &f, uint64_t lo, uint64_t hi, uint32_t n_genomes, const cq_counts *out = nullptr)
 {
     const cq::FlatImage &img = ix->H->img;
     CQ_HIP(hipSetDevice(ix->device));
     if (!ix->s_copy) CQ_HIP(hipStreamCreateWithFlags(&ix->s_copy, hipStreamNonBlocking));
     if (!ix->s_copy2) CQ_HIP(hipStreamCreateWithFlags(&ix->s_copy2, hipStreamNonBlocking));
     if (!ix->s_comp) CQ_HIP(hipStreamCreateWithFlags(&ix->s_comp, hipStreamNonBlocking));
+    if (!ix->s_comp2) CQ_HIP(hipStreamCreateWithFlags(&ix->s_comp2, hipStreamNonBlocking));
+    if (!ix->ev_zeroed) CQ_HIP(hipEventCreateWithFlags(&ix->ev_zeroed, hipEventDisableTiming));
+    if (!ix->ev_comp2) CQ_HIP(hipEventCreateWithFlags(&ix->ev_comp2, hipEventDisableTiming));
     if (!ix->s_widen) CQ_HIP(make_widen_stream(ix));
     const uint64_t cw = cq_counter_words(n_genomes);
     const uint64_t nl = img.n_leaves[0] + img.n_leaves[1];
@@ -1192,6 +1236,14 @@ int classify_range(cq_index *ix, int mode, const Feed &f, uint64_t lo, uint64_t 
         d_rc = ix->d_rc;
         CQ_HIP(hipMemsetAsync(d_rc, 0, nl * 4, ix->s_comp));
     }
+    // Two compute queues, even and odd chunks: a chunk's kernel is a persistent grid that ramps up and drains; run one
+    // after the other on ONE queue, 24 chunks cost 8-15 % more than the same reads in one launch (measured: 0.93-1.0 ms
+    // per 2 M-read chunk where 50 M reads take 19.2-21.6 ms).  On two queues the next chunk's workgroups move into the
+    // CUs as the previous chunk's leave.  Every output is an atomic sum, each slot has its own slow-path list.
+    // (CAMMIQ_TWO_STREAMS=0: one queue, A/B knob.)
+    const bool two = !(getenv("CAMMIQ_TWO_STREAMS") && atoi(getenv("CAMMIQ_TWO_STREAMS")) == 0);
+    CQ_HIP(hipEventRecord(ix->ev_zeroed, ix->s_comp));
+    if (two) CQ_HIP(hipStreamWaitEvent(ix->s_comp2, ix->ev_zeroed, 0));
     const bool ascii = f.packed == nullptr && f.tight == nullptr;
     int rc = CQ_OK;
     uint64_t c = 0;
@@ -1201,32 +1253,51 @@ int classify_range(cq_index *ix, int mode, const Feed &f, uint64_t lo, uint64_t 
     tdev("query_start", 0, ix->s_comp);
     // inside the loop a failed HIP call ends the loop instead of returning: copies from the caller's memory may be in flight
 #define CQ_HIPB(call) if (hipError_t e_ = (call)) { rc = fail(CQ_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); break; } else (void)0
-    // Chunk schedule: equal chunks.  (Ramping the ends -- 1/4 and 1/2 chunks first and last, so that the first copy
-    // and the last kernel expose less -- was measured on configs[2]: 31.26 / 31.22 ms against 31.55 / 31.12 ms without,
-    // A/B/A/B on one box: the copy queue is the critical path, the last kernel's 0.9 ms is all a ramp can shorten.)
-    // Round 4: the copies are the critical path (25 B per read at the link's ~55 GB/s against ~0.45 ms of kernel per M
-    // reads), so what a schedule can take off the bracket is its END: the last chunk's kernel runs after the last copy
-    // with nothing beside it.  The tail is cut finer (1/2, 1/4, 1/4 of a chunk by default; CAMMIQ_CHUNK_TAIL=0 for equal
-    // chunks), and so is the head.
+    // Chunk schedule: equal chunks, the LAST one cut finer (1/2, 1/4, 1/4: CAMMIQ_CHUNK_TAIL=0 for equal chunks) -- where the
+    // link bounds the bracket the last chunk's kernel runs after the last copy with nothing beside it.  A finer HEAD was
+    // measured too and buys nothing: the kernels consume reads about as fast as the link delivers them, so the first 2 M
+    // reads are done ~2 ms into the query either way, and four more chunks cost the host four more rounds of enqueueing
+    // (28.9-29.7 ms against 28.2-29.0 ms, A/B in one process; profiles/r04_hostfed_*).
     std::vector<uint64_t> sched;
     {
         const int tail_on = getenv("CAMMIQ_CHUNK_TAIL") ? atoi(getenv("CAMMIQ_CHUNK_TAIL")) : 1;
         const uint64_t chunk = chunk_reads();
         uint64_t left = hi - lo;
         std::vector<uint64_t> tail;
-        if (tail_on && left >= 4 * chunk && !ascii) {
-            // ... and the HEAD the other way round (1/4, 1/4, 1/2): the first kernel starts after a quarter of a chunk's copy
-            // instead of a whole one, which is what a board whose kernels, not the link, bound the bracket gets back
+        if (tail_on && left >= 3 * chunk && !ascii) {
             tail = {chunk / 2, chunk / 4, chunk - chunk / 2 - chunk / 4};
-            left -= 2 * chunk;
-            sched = {chunk / 4, chunk / 4, chunk - 2 * (chunk / 4)};
+            left -= chunk;
         }
         while (left > 0) { const uint64_t n = std::min(chunk, left); sched.push_back(n); left -= n; }
         sched.insert(sched.end(), tail.begin(), tail.end());
     }
+    // Packed feeds: the shortest and the longest length of every chunk, found by a thread that runs ahead of the loop
+    // (2 MB of lengths per chunk: ~0.2 ms of the ~0.5 ms the host spends per chunk when it scans them itself, on a loop
+    // that is within a factor of two of bounding the bracket).
+    struct Prescan {
+        std::vector<uint32_t> lmin, lmax;
+        std::atomic<size_t> ready{0};
+        std::thread th;
+        ~Prescan() { if (th.joinable()) th.join(); }
+    } pre;
+    if (!ascii && !sched.empty()) {
+        pre.lmin.assign(sched.size(), 255);
+        pre.lmax.assign(sched.size(), 0);
+        const uint8_t *L = f.lens + lo;
+        pre.th = std::thread([&pre, &sched, L] {
+            uint64_t r0 = 0;
+            for (size_t ci = 0; ci < sched.size(); r0 += sched[ci], ci++) {
+                uint32_t mn = 255, mx = 0;
+                for (uint64_t r = r0, e = r0 + sched[ci]; r < e; r++) { const uint32_t l = L[r]; mn = l < mn ? l : mn; mx = l > mx ? l : mx; }
+                pre.lmin[ci] = mn; pre.lmax[ci] = mx;
+                pre.ready.store(ci + 1, std::memory_order_release);
+            }
+        });
+    }
     uint64_t c0 = lo;
     for (size_t ci = 0; ci < sched.size() && rc == CQ_OK; c0 += sched[ci], ci++, c++) {
         cq_index::Slot &sl = ix->slot[c % kSlots];
+        hipStream_t s_k = (two && (c & 1)) ? ix->s_comp2 : ix->s_comp;   // this chunk's kernels
         const uint64_t n = sched[ci];
         uint64_t max_len = f.max_len;
         uint32_t sw = f.sw;
@@ -1285,15 +1356,16 @@ int classify_range(cq_index *ix, int mode, const Feed &f, uint64_t lo, uint64_t 
         CQ_HIPB(hipEventRecord(sl.copied, ix->s_copy));
         tdev("h2d_end", c, ix->s_copy);
         // The lengths.  The lane grid is sized by the longest read: take it from the lengths themselves (a max_len that
-        // is too small would silently drop windows) and refuse lengths the rows cannot hold.  The scan runs while the
-        // row copy is in flight -- in front of it the scan delayed every transfer (measured: 1 540 -> 1 325 Mreads/s).
+        // is too small would silently drop windows) and refuse lengths the rows cannot hold.  The row copy is in flight
+        // by now -- in front of it a scan delayed every transfer (measured: 1 540 -> 1 325 Mreads/s).
         // A chunk whose reads all have ONE length (what a sequencing run delivers) does not send its lengths at all:
         // the device array is filled on the device (2 MB less per 50 MB chunk on the link that bounds the bracket).
         bool lens_uniform = false;
         uint32_t longest = 0;
         if (!ascii) {
-            uint32_t shortest = 255;
-            for (uint64_t r = 0; r < n; r++) { const uint32_t l = src_lens[r]; longest = std::max(longest, l); shortest = std::min(shortest, l); }
+            while (pre.ready.load(std::memory_order_acquire) <= ci) _mm_pause();
+            longest = pre.lmax[ci];
+            const uint32_t shortest = pre.lmin[ci];
             if (longest > (f.tight ? f.sb * 4u : sw * 16u)) { rc = fail(CQ_ERR_ARG, "cq_query_packed: a length exceeds what a row of this stride holds"); break; }
             max_len = std::max<uint64_t>(max_len, longest);
             const bool fill_off = getenv("CAMMIQ_LENS_FILL") && atoi(getenv("CAMMIQ_LENS_FILL")) == 0;   // A/B knob
@@ -1310,21 +1382,30 @@ int classify_range(cq_index *ix, int mode, const Feed &f, uint64_t lo, uint64_t 
             CQ_HIPB(cq::launch_widen_rows(sl.d_tight, f.sb, sl.d_packed, sw, n, ix->s_widen));
             CQ_HIPB(hipEventRecord(sl.widened, ix->s_widen));
             tdev("widen_end", c, ix->s_widen);
-            CQ_HIPB(hipStreamWaitEvent(ix->s_comp, sl.widened, 0));
+            CQ_HIPB(hipStreamWaitEvent(s_k, sl.widened, 0));
         } else
-            CQ_HIPB(hipStreamWaitEvent(ix->s_comp, sl.copied, 0));
-        CQ_HIPB(hipStreamWaitEvent(ix->s_comp, sl.copied_lens, 0));
-        tdev("kernel_begin", c, ix->s_comp);
-        rc = cq_query_device(ix, mode, sl.d_packed, sl.d_lens, n, sw, (uint32_t)max_len, n_genomes, ix->d_ctr, d_rc,
-                             ix->s_comp);
+            CQ_HIPB(hipStreamWaitEvent(s_k, sl.copied, 0));
+        CQ_HIPB(hipStreamWaitEvent(s_k, sl.copied_lens, 0));
+        tdev("kernel_begin", c, s_k);
+        rc = query_device_impl(ix, mode, sl.d_packed, sl.d_lens, n, sw, (uint32_t)max_len, n_genomes, ix->d_ctr, d_rc, s_k,
+                               OvfRef{&sl.d_ovf_list, &sl.d_ovf_count, &sl.ovf_cap});
         if (rc != CQ_OK) break;
-        CQ_HIPB(hipEventRecord(sl.done, ix->s_comp));
-        tdev("kernel_end", c, ix->s_comp);
+        CQ_HIPB(hipEventRecord(sl.done, s_k));
+        tdev("kernel_end", c, s_k);
         thost("enqueued", c);
     }
 #undef CQ_HIPB
-    if (hipStreamSynchronize(ix->s_comp) != hipSuccess && rc == CQ_OK) rc = fail(CQ_ERR_HIP, "classify kernel failed");
-    thost("kernels_done", c);
+    if (rc == CQ_OK && two) {   // the even queue takes the odd one's kernels in: what follows on s_comp follows every kernel
+        if (hipEventRecord(ix->ev_comp2, ix->s_comp2) != hipSuccess || hipStreamWaitEvent(ix->s_comp, ix->ev_comp2, 0) != hipSuccess)
+            rc = fail(CQ_ERR_HIP, "joining the two compute queues failed");
+    }
+    if (rc == CQ_OK && out && mode == CQ_MODE_P && d_rc)
+        rc = narrow_start(ix, img.n_leaves[0], img.n_leaves[1], out->rcount_u, out->rcount_d);   // queued behind the last kernel, no host wait in between
+    if (!ix->narrow_inflight) {   // (with rcount on its way the wait is narrow_finish's: it ends behind every kernel)
+        if (hipStreamSynchronize(ix->s_comp) != hipSuccess && rc == CQ_OK) rc = fail(CQ_ERR_HIP, "classify kernel failed");
+        if (two && hipStreamSynchronize(ix->s_comp2) != hipSuccess && rc == CQ_OK) rc = fail(CQ_ERR_HIP, "classify kernel failed");
+        thost("kernels_done", c);
+    }
     if (rc != CQ_OK) {   // an error may have left copies from the caller's memory in flight with no kernel behind them
         (void)hipStreamSynchronize(ix->s_copy);
         (void)hipStreamSynchronize(ix->s_copy2);
@@ -1445,15 +1526,16 @@ int ensure_narrow(cq_index *ix, uint64_t nl)
 //                   stores); the escaped entries are written last.
 // Bit-exact with the plain copy (tests: leaves forced past 255, the escape list overrun -> *fell_back = true, plain copy).
 // What a query hands the ILP is unchanged: uint32 per leaf in decode order (query.cpp:1161,1176-1177).
-int fetch_rcount_narrow(cq_index *ix, uint64_t n_u, uint64_t n_d, uint32_t *dst_u, uint32_t *dst_d, bool *fell_back)
+// narrow_start queues the kernel on s_comp (behind whatever is queued there) and wakes the pool; narrow_finish waits for the
+// threads and writes the escapes.  Not started (no pool, too few leaves): narrow_inflight stays false, the caller copies.
+int narrow_start(cq_index *ix, uint64_t n_u, uint64_t n_d, uint32_t *dst_u, uint32_t *dst_d)
 {
     const uint64_t nl = n_u + n_d;
-    *fell_back = true;
+    ix->narrow_inflight = false;
     int rc = ensure_narrow(ix, nl);
     if (rc != CQ_OK) return rc;
     if (!ix->pool) return CQ_OK;
     WidenPool &P = *ix->pool;
-    const unsigned W = (unsigned)P.th.size();
     PipeTrace *tr = ix->trace;
     const uint64_t seg = narrow_seg(), nseg = (nl + seg - 1) / seg;
     if (ix->flags_cap < nseg + 1) return fail(CQ_ERR_ARG, "narrow rcount: segment size changed under a live handle");
@@ -1476,7 +1558,22 @@ int fetch_rcount_narrow(cq_index *ix, uint64_t n_u, uint64_t n_d, uint32_t *dst_
         P.job_seq++;
     }
     P.cv.notify_all();
-    // the kernel's completion is watched too: if it failed no flag will ever come
+    ix->narrow_inflight = true;
+    ix->narrow_nseg = nseg;
+    return CQ_OK;
+}
+
+int narrow_finish(cq_index *ix, uint64_t n_u, uint32_t *dst_u, uint32_t *dst_d, bool *fell_back)
+{
+    *fell_back = true;
+    if (!ix->narrow_inflight) return CQ_OK;
+    ix->narrow_inflight = false;
+    WidenPool &P = *ix->pool;
+    const unsigned W = (unsigned)P.th.size();
+    PipeTrace *tr = ix->trace;
+    const uint64_t nseg = ix->narrow_nseg;
+    const uint32_t epoch = ix->narrow_epoch;
+    // the kernel's completion is watched too: if it (or a classify kernel before it) failed no flag will ever come
     hipError_t bad = hipSuccess;
     const volatile uint32_t *flags = ix->h_flags;
     uint64_t spins = 0;
@@ -1488,7 +1585,7 @@ int fetch_rcount_narrow(cq_index *ix, uint64_t n_u, uint64_t n_d, uint32_t *dst_
         }
     }
     if (tr) tr->host("widened", (int)nseg);
-    if (bad != hipSuccess) return fail(CQ_ERR_HIP, std::string("narrow rcount kernel: ") + hipGetErrorString(bad));
+    if (bad != hipSuccess) return fail(CQ_ERR_HIP, std::string("classify / narrow rcount kernel: ") + hipGetErrorString(bad));
     CQ_HIP(hipEventSynchronize(ix->ev_narrow));
     if (flags[nseg] != epoch) return fail(CQ_ERR_HIP, "narrow rcount kernel ended without its final flag");
     std::atomic_thread_fence(std::memory_order_acquire);
@@ -1512,10 +1609,13 @@ int fetch_counts(cq_index *ix, int mode, uint32_t n_genomes, cq_counts *out, uin
     const uint64_t G1 = (uint64_t)n_genomes + 1, cw = cq_counter_words(n_genomes);
     CQ_HIP(hipSetDevice(ix->device));
     std::vector<uint64_t> ctr(cw, 0);
-    CQ_HIP(hipMemcpy(ctr.data(), ix->d_ctr, cw * 8, hipMemcpyDeviceToHost));
+    if (mode == CQ_MODE_P && ix->d_rc && !ix->narrow_inflight) {   // (one device: classify_range has started it behind its last kernel)
+        int rc = narrow_start(ix, img.n_leaves[0], img.n_leaves[1], out->rcount_u, out->rcount_d);
+        if (rc != CQ_OK) return rc;
+    }
     if (mode == CQ_MODE_P && ix->d_rc) {
         bool plain = true;
-        int rc = fetch_rcount_narrow(ix, img.n_leaves[0], img.n_leaves[1], out->rcount_u, out->rcount_d, &plain);
+        int rc = narrow_finish(ix, img.n_leaves[0], out->rcount_u, out->rcount_d, &plain);   // returns behind every kernel of the query
         if (rc != CQ_OK) return rc;
         if (plain) {
             rc = copy_out(ix, out->rcount_u, ix->d_rc, img.n_leaves[0] * 4);
@@ -1523,6 +1623,8 @@ int fetch_counts(cq_index *ix, int mode, uint32_t n_genomes, cq_counts *out, uin
             if (rc != CQ_OK) return rc;
         }
     }
+    CQ_HIP(hipStreamSynchronize(ix->s_comp));   // (SC mode, or rcount the plain way: nothing has waited for the kernels yet on the one-device path)
+    CQ_HIP(hipMemcpy(ctr.data(), ix->d_ctr, cw * 8, hipMemcpyDeviceToHost));
     memcpy(out->cnt_u, ctr.data(), G1 * 8);
     memcpy(out->cnt_d, ctr.data() + G1, G1 * 8);
     out->nundet = ctr[CQ_CTR_NUNDET(n_genomes)];
@@ -1547,7 +1649,7 @@ int query_one(cq_index *ix, int mode, const Feed &f, uint64_t n_reads, uint32_t 
         }
         PipeTrace trace;
         ix->trace = trace.on() ? &trace : nullptr;
-        rc = classify_range(ix, mode, f, 0, n_reads, n_genomes);
+        rc = classify_range(ix, mode, f, 0, n_reads, n_genomes, out);
         uint64_t flags = 0;
         if (rc == CQ_OK) rc = fetch_counts(ix, mode, n_genomes, out, &flags);
         if (ix->trace) { trace.host("query_done", 0); trace.dump(); ix->trace = nullptr; }

@@ -910,9 +910,9 @@ hipError_t launch_widen_rows(const uint8_t *tight, uint32_t sb, uint32_t *rows, 
 // bytes, made a 1.5 ms transfer take 4.4 ms).  The workgroup that finishes last publishes the number of escapes and the
 // final flag flags[n_segments].  *esc_count may end above esc_cap: the host then falls back to the plain uint32 copy.
 __global__ void __launch_bounds__(256) narrow_rcount_kernel(const uint32_t *__restrict__ rc, uint64_t n, uint8_t *__restrict__ out8,
-                                                            uint64_t seg, uint32_t *__restrict__ flags, uint32_t epoch, uint2 *__restrict__ esc,
-                                                            uint32_t *__restrict__ esc_count, uint32_t esc_cap, uint32_t *__restrict__ blocks_done,
-                                                            uint32_t *__restrict__ host_esc_count)
+                                                            uint64_t seg, uint64_t n_seg, uint32_t *__restrict__ flags, uint32_t epoch,
+                                                            uint2 *__restrict__ esc, uint32_t *__restrict__ esc_count, uint32_t esc_cap,
+                                                            uint32_t *__restrict__ blocks_done, uint32_t *__restrict__ host_esc_count)
 {
     auto squeeze = [&](uint32_t v, uint64_t idx) -> uint32_t {
         if (v < 255u) return v;
@@ -920,31 +920,34 @@ __global__ void __launch_bounds__(256) narrow_rcount_kernel(const uint32_t *__re
         if (at < esc_cap) esc[at] = make_uint2((uint32_t)idx, v);
         return 255u;
     };
-    const uint64_t lo = (uint64_t)blockIdx.x * seg, hi = lo + seg < n ? lo + seg : n;   // seg is a multiple of 16: lo stays 16-entry aligned
-    const uint64_t hi16 = lo + ((hi - lo) & ~(uint64_t)15);
-    for (uint64_t i = lo + (uint64_t)threadIdx.x * 16; i < hi16; i += 256 * 16) {
-        const uint4 *src = (const uint4 *)(rc + i);
-        uint32_t w[4];
+    // A FEW workgroups walk the segments in order (workgroup b takes b, b + grid, ...): the segments reach the host one
+    // after the other at the link's rate, so the host's threads widen segment k while k + 1 .. are still on the wire.
+    // (One workgroup per segment, all resident at once, shares the link among all of them: every flag came at the end.)
+    for (uint64_t sg = blockIdx.x; sg < n_seg; sg += gridDim.x) {
+        const uint64_t lo = sg * seg, hi = lo + seg < n ? lo + seg : n;   // seg is a multiple of 16: lo stays 16-entry aligned
+        const uint64_t hi16 = lo + ((hi - lo) & ~(uint64_t)15);
+        for (uint64_t i = lo + (uint64_t)threadIdx.x * 16; i < hi16; i += 256 * 16) {
+            const uint4 *src = (const uint4 *)(rc + i);
+            uint32_t w[4];
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const uint4 v = src[q];
-            const uint64_t i0 = i + (uint64_t)q * 4;
-            w[q] = squeeze(v.x, i0) | squeeze(v.y, i0 + 1) << 8 | squeeze(v.z, i0 + 2) << 16 | squeeze(v.w, i0 + 3) << 24;
+            for (int q = 0; q < 4; q++) {
+                const uint4 v = src[q];
+                const uint64_t i0 = i + (uint64_t)q * 4;
+                w[q] = squeeze(v.x, i0) | squeeze(v.y, i0 + 1) << 8 | squeeze(v.z, i0 + 2) << 16 | squeeze(v.w, i0 + 3) << 24;
+            }
+            *(uint4 *)(out8 + i) = make_uint4(w[0], w[1], w[2], w[3]);
         }
-        *(uint4 *)(out8 + i) = make_uint4(w[0], w[1], w[2], w[3]);
+        for (uint64_t i = hi16 + threadIdx.x; i < hi; i += 256) out8[i] = (uint8_t)squeeze(rc[i], i);
+        __threadfence_system();   // this lane's bytes are on the host before the flag can be
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(flags + sg, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-    for (uint64_t i = hi16 + threadIdx.x; i < hi; i += 256) out8[i] = (uint8_t)squeeze(rc[i], i);
-    __threadfence_system();   // this lane's bytes are on the host before the flag can be
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __hip_atomic_store(flags + blockIdx.x, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        if (atomicAdd(blocks_done, 1u) == gridDim.x - 1) {   // every other workgroup's escapes are counted (their atomics precede their ticket)
-            __threadfence();
-            *host_esc_count = __hip_atomic_load(esc_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            *blocks_done = 0;
-            __threadfence_system();
-            __hip_atomic_store(flags + gridDim.x, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
+    if (threadIdx.x == 0 && atomicAdd(blocks_done, 1u) == gridDim.x - 1) {   // every other workgroup's escapes are counted (their atomics precede their ticket)
+        __threadfence();
+        *host_esc_count = __hip_atomic_load(esc_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *blocks_done = 0;
+        __threadfence_system();
+        __hip_atomic_store(flags + n_seg, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -953,9 +956,14 @@ hipError_t launch_narrow_rcount(const uint32_t *rc, uint64_t n, uint8_t *host_ou
 {
     if (n == 0) return hipSuccess;
     if (seg == 0 || (seg & 15u)) return hipErrorInvalidValue;
-    const uint64_t grid = (n + seg - 1) / seg;
-    hipLaunchKernelGGL(narrow_rcount_kernel, dim3((unsigned)grid), dim3(256), 0, stream, rc, n, host_out8, seg, host_flags, epoch, esc, esc_count, esc_cap,
-                       blocks_done, host_esc_count);
+    const uint64_t n_seg = (n + seg - 1) / seg;
+    // workgroups in flight: enough 16-byte stores outstanding to keep the link busy (64 x 256 lanes x 16 B = 256 KB per step),
+    // few enough that the segments arrive in order (CAMMIQ_NARROW_WGS: tuning knob)
+    uint64_t grid = 64;
+    if (const char *v = getenv("CAMMIQ_NARROW_WGS")) grid = (uint64_t)std::max(1, atoi(v));
+    if (grid > n_seg) grid = n_seg;
+    hipLaunchKernelGGL(narrow_rcount_kernel, dim3((unsigned)grid), dim3(256), 0, stream, rc, n, host_out8, seg, n_seg, host_flags, epoch, esc, esc_count,
+                       esc_cap, blocks_done, host_esc_count);
     return hipGetLastError();
 }
 
