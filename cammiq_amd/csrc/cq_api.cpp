@@ -1399,7 +1399,8 @@ int classify_range(cq_index *ix, int mode, const Feed &f, uint64_t lo, uint64_t 
         if (hipEventRecord(ix->ev_comp2, ix->s_comp2) != hipSuccess || hipStreamWaitEvent(ix->s_comp, ix->ev_comp2, 0) != hipSuccess)
             rc = fail(CQ_ERR_HIP, "joining the two compute queues failed");
     }
-    if (rc == CQ_OK && out && mode == CQ_MODE_P && d_rc)
+    const bool early = !(getenv("CAMMIQ_EARLY_NARROW") && atoi(getenv("CAMMIQ_EARLY_NARROW")) == 0);   // A/B / debugging knob
+    if (rc == CQ_OK && out && mode == CQ_MODE_P && d_rc && early)
         rc = narrow_start(ix, img.n_leaves[0], img.n_leaves[1], out->rcount_u, out->rcount_d);   // queued behind the last kernel, no host wait in between
     if (!ix->narrow_inflight) {   // (with rcount on its way the wait is narrow_finish's: it ends behind every kernel)
         if (hipStreamSynchronize(ix->s_comp) != hipSuccess && rc == CQ_OK) rc = fail(CQ_ERR_HIP, "classify kernel failed");
