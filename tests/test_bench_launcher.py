@@ -31,7 +31,7 @@ def test_self_launch_returns_the_ranks_status_without_a_gpu():
 
 
 def test_configs4_sizing_rule():
-    """tools/configs4.py shrinks configs[4]'s genomes to what the host can build (the index build peaks at ~175 bytes of
+    """tools/configs4.py shrinks configs[4]'s genomes to what the host can build (the index build is budgeted at ~90 bytes of
     host memory per marker; a one-GPU lease is capped near 270 GiB): full size on a big box, proportionally less on a
     small one, and the at-size GPU test skips below 400 kbp genomes."""
     import sys
@@ -39,10 +39,10 @@ def test_configs4_sizing_rule():
     import configs4
     full, _, _ = configs4.size_for_this_box(15_000, 3_450_000, host_budget_bytes=400e9, shm_bytes=400e9)
     assert full == 3_450_000
-    half, _, _ = configs4.size_for_this_box(15_000, 3_450_000, host_budget_bytes=150e9, shm_bytes=400e9)
+    half, _, _ = configs4.size_for_this_box(15_000, 3_450_000, host_budget_bytes=100e9, shm_bytes=400e9)
     assert 1_000_000 < half < 3_450_000
     markers = 15_000 * half * configs4.MARKERS_PER_GENOME_BASE
-    assert markers * configs4.BYTES_PER_MARKER_HOST_PEAK <= 0.72 * 150e9 * 1.001
+    assert markers * configs4.BYTES_PER_MARKER_HOST_PEAK <= 0.72 * 100e9 * 1.001
     tiny, _, _ = configs4.size_for_this_box(15_000, 3_450_000, host_budget_bytes=20e9, shm_bytes=400e9)
     assert tiny < 400_000
 

@@ -13,6 +13,7 @@ for f in cq_decode cq_layout cq_pack cq_cache; do
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC "$@" -c cq_api.cpp -o "$b/cq_api.o" &
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC "$@" -c cq_kernels.hip -o "$b/cq_kernels.o" &
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC "$@" -c cq_layout_gpu.hip -o "$b/cq_layout_gpu.o" &
 wait
 mkdir -p "$root/variants"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o "$root/variants/libcammiq_$name.so" "$b"/*.o -lpthread -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib

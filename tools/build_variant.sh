@@ -13,6 +13,6 @@ cp "$src" "$b/cq_kernels.hip"
 cd "$root/cammiq_amd/csrc"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I"$root/cammiq_amd/csrc" "$@" -c "$b/cq_kernels.hip" -o "$b/cq_kernels.o"
 mkdir -p "$root/variants"
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o "$root/variants/libcammiq_$name.so" build/cq_decode.o build/cq_layout.o build/cq_pack.o build/cq_cache.o build/cq_api.o "$b/cq_kernels.o" -lpthread -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o "$root/variants/libcammiq_$name.so" build/cq_decode.o build/cq_layout.o build/cq_pack.o build/cq_cache.o build/cq_api.o build/cq_layout_gpu.o "$b/cq_kernels.o" -lpthread -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib
 rm -rf "$b"
 echo "built variants/libcammiq_$name.so"

@@ -36,7 +36,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-BYTES_PER_MARKER_HOST_PEAK = 175     # files in /dev/shm + decoded tables + sort buffers + table image, measured
+BYTES_PER_MARKER_HOST_PEAK = 90      # round 4 (table laid out on the device): index files in /dev/shm (~15 B) + decoded keys, codes and
+                                     # leaves + leaf refIDs + this tool's own rcount copies; measured 85.6 GB of peak RSS at 1.258e9 markers = 68 B
+                                     # (round 3, host layout: 163 GB = 130 B, budgeted at 175)
 MARKERS_PER_GENOME_BASE = 2 / 69 * 0.839   # two strands, one marker per 69 positions, minus block-straddling / shared-once losses
 
 

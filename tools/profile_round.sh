@@ -12,7 +12,7 @@
 #      slots, WRITE_SIZE 2 -- MI355X_MICROARCH.md "rocprofv3 PMC slots") -> gpurun_out/prof_TAG/traffic.json
 #   3. tools/gather_bench at the workload's table size          -> gpurun_out/prof_TAG/gather.txt
 # Copy the results into profiles/ afterwards (see profiles/README.md); tools/merge_traffic.py folds
-# traffic.json + gather.txt into profiles/traffic_r02.json under the workload's key.
+# traffic.json + gather.txt into profiles/traffic_rNN.json under the workload's key (--round rNN).
 set -euo pipefail
 root="$(cd "$(dirname "$0")/.." && pwd)"
 tag=$1; shift
