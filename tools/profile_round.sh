@@ -37,7 +37,7 @@ for c in ("FETCH_SIZE","WRITE_SIZE"):
     d=collections.defaultdict(float)
     for f in glob.glob(f"{out}/pmc_{c}/**/*counter_collection.csv",recursive=True):
         for r in csv.DictReader(open(f)):
-            if r["Counter_Name"]==c and ("Lb0" in r["Kernel_Name"] or "false" in r["Kernel_Name"]):
+            if r["Counter_Name"]==c and "classify_kernel" in r["Kernel_Name"] and ("Lb0" in r["Kernel_Name"] or "false" in r["Kernel_Name"]):   # the fast classify kernel only (round 4: layout and calibration kernels also carry a `false`)
                 d[r["Dispatch_Id"]]+=float(r["Counter_Value"])
     v=list(d.values())
     res[c+"_KB_per_launch"]=sum(v)/len(v); res[c+"_launches"]=len(v)
