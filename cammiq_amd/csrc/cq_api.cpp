@@ -843,7 +843,8 @@ namespace {
 // other on the caller's stream), or a staging slot's (host-fed pipeline: the kernels of consecutive chunks overlap).
 struct OvfRef { uint32_t **list; uint32_t **count; uint64_t *cap; };
 int query_device_impl(cq_index *ix, int mode, const uint32_t *d_packed, const uint8_t *d_lens, uint64_t n_reads, uint32_t stride_words,
-                      uint32_t max_len, uint32_t n_genomes, uint64_t *d_counters, uint32_t *d_rcount, hipStream_t st, OvfRef ovf);
+                      uint32_t max_len, uint32_t n_genomes, uint64_t *d_counters, uint32_t *d_rcount, hipStream_t st, OvfRef ovf,
+                      const uint8_t *d_tight = nullptr, uint32_t tight_sb = 0);
 }  // namespace
 
 extern "C" {
@@ -861,11 +862,12 @@ int cq_query_device(cq_index *ix, int mode, const uint32_t *d_packed, const uint
 
 namespace {
 int query_device_impl(cq_index *ix, int mode, const uint32_t *d_packed, const uint8_t *d_lens, uint64_t n_reads, uint32_t stride_words,
-                      uint32_t max_len, uint32_t n_genomes, uint64_t *d_counters, uint32_t *d_rcount, hipStream_t st, OvfRef ovf)
+                      uint32_t max_len, uint32_t n_genomes, uint64_t *d_counters, uint32_t *d_rcount, hipStream_t st, OvfRef ovf,
+                      const uint8_t *d_tight, uint32_t tight_sb)
 {
     if (ix->device < 0) return fail(CQ_ERR_NO_DEVICE, "index was loaded host-only (CQ_DEVICE_NONE); no CPU classify path exists");
     if (mode != CQ_MODE_P && mode != CQ_MODE_SC) return fail(CQ_ERR_ARG, "cq_query_device: unknown mode");
-    if (!d_counters || (n_reads && (!d_packed || !d_lens)) || stride_words == 0 || stride_words > 16)
+    if (!d_counters || (n_reads && ((!d_packed && !d_tight) || !d_lens)) || stride_words == 0 || stride_words > 16)
         return fail(CQ_ERR_ARG, "cq_query_device: bad argument");
     if (n_reads > 0x7FFFFFFFull) return fail(CQ_ERR_ARG, "cq_query_device: more than 2^31-1 reads in one call");
     const cq::FlatImage &img = ix->H->img;
@@ -886,7 +888,9 @@ int query_device_impl(cq_index *ix, int mode, const uint32_t *d_packed, const ui
     if (max_len == 0 || max_len > stride_words * 16) max_len = stride_words * 16;
     if (max_len > 255) max_len = 255;
     cq::QueryArgs a{};
-    a.packed = d_packed;
+    a.packed = d_tight ? nullptr : d_packed;
+    a.tight = d_tight;          // rows as they crossed the link: the kernel's staging widens them (host-fed tight door)
+    a.tight_sb = tight_sb;
     a.lens = d_lens;
     a.n_reads = n_reads;
     a.stride_words = stride_words;
@@ -1152,7 +1156,7 @@ void warm_workspace(cq_index *ix, LoadTimer *lt)
     lap("  priority stream");
     for (auto &sl : ix->slot) {
         (void)slot_reserve(sl, kChunk, 8, true);   // with the page-locked host side ASCII reads are packed into (cq_query): 19.8 instead of 25.9 ms per 10 M reads
-        if (!sl.d_tight && hipMalloc((void **)&sl.d_tight, kChunk * 32) == hipSuccess) sl.cap_tight = kChunk * 32;   // tight rows of up to 128 bases
+        if (!sl.d_tight && hipMalloc((void **)&sl.d_tight, kChunk * 32 + 16) == hipSuccess) sl.cap_tight = kChunk * 32 + 16;   // tight rows of up to 128 bases
     }
     lap("  staging slots");
     for (int b = 0; b < 2; b++) {
@@ -1341,11 +1345,11 @@ int classify_range(cq_index *ix, int mode, const Feed &f, uint64_t lo, uint64_t 
         // -- same box, A/B/A/B -- so it is not done.)
         const uint8_t *src_tight = f.tight ? f.tight + (size_t)c0 * f.sb : nullptr;
         if (f.tight) {   // fewer bytes over the link: the rows arrive tight and are widened on the device
-            if (sl.cap_tight < (size_t)n * f.sb) {
+            if (sl.cap_tight < (size_t)n * f.sb + 16) {   // + 16: the kernel's last lane reads whole 16-byte pieces
                 if (sl.d_tight) (void)hipFree(sl.d_tight);
                 sl.d_tight = nullptr; sl.cap_tight = 0;
-                CQ_HIPB(hipMalloc((void **)&sl.d_tight, (size_t)n * f.sb));
-                sl.cap_tight = (size_t)n * f.sb;
+                CQ_HIPB(hipMalloc((void **)&sl.d_tight, (size_t)n * f.sb + 16));
+                sl.cap_tight = (size_t)n * f.sb + 16;
             }
             tdev("h2d_begin", c, ix->s_copy);
             CQ_HIPB(hipMemcpyAsync(sl.d_tight, src_tight, (size_t)n * f.sb, hipMemcpyHostToDevice, ix->s_copy));
@@ -1376,7 +1380,13 @@ int classify_range(cq_index *ix, int mode, const Feed &f, uint64_t lo, uint64_t 
         if (lens_uniform) CQ_HIPB(hipMemsetAsync(sl.d_lens, (int)longest, n, ix->s_copy2));
         else CQ_HIPB(hipMemcpyAsync(sl.d_lens, src_lens, n, hipMemcpyHostToDevice, ix->s_copy2));
         CQ_HIPB(hipEventRecord(sl.copied_lens, ix->s_copy2));
-        if (f.tight) {   // widen on a queue of its own: in front of the classify kernel it would cost the chunk ~0.1 ms
+        // Tight rows are widened by the classify kernel's own staging (a byte image of the sub-tile through LDS): no widening
+        // kernel sharing the GPU with the classify kernels, no second copy of the rows in HBM.  CAMMIQ_FUSED_WIDEN=0: the
+        // separate widening kernel on its high-priority queue, as before (A/B knob).
+        const bool fused = f.tight && !(getenv("CAMMIQ_FUSED_WIDEN") && atoi(getenv("CAMMIQ_FUSED_WIDEN")) == 0);
+        if (fused) {
+            CQ_HIPB(hipStreamWaitEvent(s_k, sl.copied, 0));
+        } else if (f.tight) {   // widen on a queue of its own: in front of the classify kernel it would cost the chunk ~0.1 ms
             CQ_HIPB(hipStreamWaitEvent(ix->s_widen, sl.copied, 0));
             tdev("widen_begin", c, ix->s_widen);
             CQ_HIPB(cq::launch_widen_rows(sl.d_tight, f.sb, sl.d_packed, sw, n, ix->s_widen));
@@ -1388,7 +1398,7 @@ int classify_range(cq_index *ix, int mode, const Feed &f, uint64_t lo, uint64_t 
         CQ_HIPB(hipStreamWaitEvent(s_k, sl.copied_lens, 0));
         tdev("kernel_begin", c, s_k);
         rc = query_device_impl(ix, mode, sl.d_packed, sl.d_lens, n, sw, (uint32_t)max_len, n_genomes, ix->d_ctr, d_rc, s_k,
-                               OvfRef{&sl.d_ovf_list, &sl.d_ovf_count, &sl.ovf_cap});
+                               OvfRef{&sl.d_ovf_list, &sl.d_ovf_count, &sl.ovf_cap}, fused ? sl.d_tight : nullptr, fused ? f.sb : 0u);
         if (rc != CQ_OK) break;
         CQ_HIPB(hipEventRecord(sl.done, s_k));
         tdev("kernel_end", c, s_k);

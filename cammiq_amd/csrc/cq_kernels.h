@@ -20,7 +20,9 @@ struct DevIndex {
 };
 
 struct QueryArgs {
-    const uint32_t *packed;  // n_reads rows of stride_words uint32
+    const uint32_t *packed;  // n_reads rows of stride_words uint32 (null when `tight` is given)
+    const uint8_t *tight;    // or: n_reads rows of tight_sb BYTES (cq_pack_reads_tight), widened by the kernel's staging itself;
+    uint32_t tight_sb;       //     the buffer must be readable 16 bytes past its last row
     const uint8_t *lens;
     uint64_t n_reads;
     uint64_t read0;          // index of packed[0] within the call's rows (set by the launcher when it cuts a call into launches)

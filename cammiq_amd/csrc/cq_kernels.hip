@@ -449,7 +449,10 @@ __device__ __forceinline__ void decide(const QueryArgs &a, const Tile &t, uint32
 // and the minimizer network's shape stop being SGPR-resident launch arguments.  Chosen by launch_classify when index
 // and batch match; results are those of the generic instantiation (tests/test_gpu_parity.py runs both).
 constexpr uint32_t magic_of_c(uint32_t d) { return d == 0 ? 0u : (uint32_t)(((1u << 19) + d - 1) / d); }
-template <int R, int CAP, bool SLOW, int H, int RL, int M>
+// TIGHT: the rows arrive as they crossed the link (a.tight: tight_sb BYTES per read) and the staging widens them itself --
+// the host-fed door's instantiations.  Its own template argument, not a launch-time branch: with the branch inside, the
+// HBM-resident instantiations (TIGHT = false: the headline path) picked up 3 VGPR spills and 16 B of scratch.
+template <int R, int CAP, bool SLOW, int H, int RL, int M, bool TIGHT = false>
 __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(CQ_WAVES_PER_EU, CQ_WAVES_PER_EU)))
 classify_kernel(DevIndex ix, QueryArgs a)
 {
@@ -508,6 +511,18 @@ classify_kernel(DevIndex ix, QueryArgs a)
         const uint32_t nr = (uint32_t)((n_reads - r0) < (uint64_t)R ? (n_reads - r0) : (uint64_t)R);
         // the sub-tile's rows are nr * sw consecutive words (any stride 1..16: rows are not padded to 16 bytes,
         // they travel over PCIe); lane l takes words 4l .. 4l+3, the last lane of a ragged tail word by word
+        if (TIGHT) {
+            // tight rows (sb bytes per read, what crossed the link): the sub-tile is nr * sb consecutive bytes, lane l takes
+            // bytes 16 l .. 16 l + 15 as four dwords (r0 is a multiple of R, so the sub-tile starts dword-aligned; the last lane
+            // may read up to 15 bytes past the sub-tile: inside the buffer's slack).  The staging below turns them into word rows.
+            const uint32_t nbytes = nr * a.tight_sb, b0 = lane * 16;
+            if (b0 < nbytes) {
+                const uint32_t *srcb = (const uint32_t *)(a.tight + r0 * (uint64_t)a.tight_sb + b0);
+                pf_row = make_uint4(srcb[0], srcb[1], srcb[2], srcb[3]);
+            }
+            if (lane < nr) pf_len = a.lens[r0 + lane];
+            return;
+        }
         const uint32_t nwords = nr * sw, w0 = lane * 4;
         const uint32_t *src = a.packed + r0 * sw + w0;
         if (w0 + 4 <= nwords) {
@@ -539,7 +554,23 @@ classify_kernel(DevIndex ix, QueryArgs a)
 
         // ---- stage the sub-tile: 2-bit rows -> LDS.  The fast path fetched them one sub-tile
         // ahead (16 B per lane, contiguous: R reads x <= 4 vectors fit one wave instruction).
-        if (!SLOW) {
+        if (!SLOW && TIGHT) {
+            // the byte image of the sub-tile goes through LDS (the hash words' area: free until the pre-pass), then every lane
+            // assembles one word of one row: bytes 4w .. 4w+3 of the read's tight row, first byte on top, zero past the row
+            const uint32_t sb = a.tight_sb, nbytes = nr * sb;
+            uint32_t *raw = t.phi;
+            if (lane * 16 < nbytes) { uint32_t *d = raw + lane * 4; d[0] = pf_row.x; d[1] = pf_row.y; d[2] = pf_row.z; d[3] = pf_row.w; }
+            wave_sync();
+            for (uint32_t j = lane; j < nr * sw; j += 64) {
+                const uint32_t r = div_small(j, sw, magic_s), w = j - r * sw, o = r * sb + 4u * w;
+                const uint32_t d0 = raw[o >> 2], d1 = raw[(o >> 2) + 1], sh = 8u * (o & 3u);
+                uint32_t v = sh ? (d0 >> sh) | (d1 << (32u - sh)) : d0;   // bytes o .. o+3 as they lie in memory
+                v = __builtin_bswap32(v);                                  // first byte on top
+                const uint32_t valid = sb - 4u * w;                        // bytes of the row this word still covers (>= 1)
+                if (valid < 4u) v &= 0xFFFFFFFFu << (8u * (4u - valid));
+                t.rows[r * swp + w] = v;
+            }   // (the wave_sync below, before the pre-pass, also covers the byte image)
+        } else if (!SLOW) {
             const uint32_t nwords = nr * sw, w = lane * 4;
             if (w < nwords) {
                 if (swp == sw) {        // odd stride: the sub-tile's image in LDS is its image in HBM, one 16-byte store per lane
@@ -557,7 +588,14 @@ classify_kernel(DevIndex ix, QueryArgs a)
         } else {
             for (uint32_t i = lane; i < nr * sw; i += 64) {
                 const uint32_t rl = i / sw, c = i - rl * sw;
-                t.rows[rl * swp + c] = a.packed[(uint64_t)a.ovf_list[r0 + rl] * sw + c];
+                if (a.tight) {   // the exact path reads its few rows byte by byte
+                    const uint8_t *p = a.tight + (uint64_t)a.ovf_list[r0 + rl] * a.tight_sb + 4u * c;
+                    uint32_t v = 0;
+                    for (uint32_t k = 0; k < 4u; k++)
+                        if (4u * c + k < a.tight_sb) v |= (uint32_t)p[k] << (24u - 8u * k);
+                    t.rows[rl * swp + c] = v;
+                } else
+                    t.rows[rl * swp + c] = a.packed[(uint64_t)a.ovf_list[r0 + rl] * sw + c];
             }
         }
         if (lane < (uint32_t)R) {
@@ -1078,30 +1116,34 @@ enum Variant { kV8 = 0, kV4 = 1, kV8h26r100 = 2, kV8h26r150 = 3, kV8h26r100m18 =
                kV8h26s7 = 6, kV8h26s8 = 7, kV8h26s10 = 8, kV8h26s7m18 = 9, kV8h26s8m18 = 10, kV8h26s10m18 = 11,
                kVSlow = 12, kNVariants = 13 };
 
-const void *variant_fn(int v)
+template <bool T>
+const void *variant_fn_t(int v)
 {
     switch (v) {
-    case kV8: return (const void *)classify_kernel<8, kFastCAP, false, 0, 0, 0>;
-    case kV4: return (const void *)classify_kernel<4, kFastCAP, false, 0, 0, 0>;
-    case kV8h26r100: return (const void *)classify_kernel<8, kFastCAP, false, 26, 100, 16>;
-    case kV8h26r150: return (const void *)classify_kernel<8, kFastCAP, false, 26, 150, 16>;
-    case kV8h26r100m18: return (const void *)classify_kernel<8, kFastCAP, false, 26, 100, 18>;
-    case kV8h26r150m18: return (const void *)classify_kernel<8, kFastCAP, false, 26, 150, 18>;
-    case kV8h26s7: return (const void *)classify_kernel<8, kFastCAP, false, 26, -7, 16>;
-    case kV8h26s8: return (const void *)classify_kernel<8, kFastCAP, false, 26, -8, 16>;
-    case kV8h26s10: return (const void *)classify_kernel<8, kFastCAP, false, 26, -10, 16>;
-    case kV8h26s7m18: return (const void *)classify_kernel<8, kFastCAP, false, 26, -7, 18>;
-    case kV8h26s8m18: return (const void *)classify_kernel<8, kFastCAP, false, 26, -8, 18>;
-    case kV8h26s10m18: return (const void *)classify_kernel<8, kFastCAP, false, 26, -10, 18>;
-    default: return (const void *)classify_kernel<kSlowR, kSlowCAP, true, 0, 0, 0>;
+    case kV8: return (const void *)classify_kernel<8, kFastCAP, false, 0, 0, 0, T>;
+    case kV4: return (const void *)classify_kernel<4, kFastCAP, false, 0, 0, 0, T>;
+    case kV8h26r100: return (const void *)classify_kernel<8, kFastCAP, false, 26, 100, 16, T>;
+    case kV8h26r150: return (const void *)classify_kernel<8, kFastCAP, false, 26, 150, 16, T>;
+    case kV8h26r100m18: return (const void *)classify_kernel<8, kFastCAP, false, 26, 100, 18, T>;
+    case kV8h26r150m18: return (const void *)classify_kernel<8, kFastCAP, false, 26, 150, 18, T>;
+    case kV8h26s7: return (const void *)classify_kernel<8, kFastCAP, false, 26, -7, 16, T>;
+    case kV8h26s8: return (const void *)classify_kernel<8, kFastCAP, false, 26, -8, 16, T>;
+    case kV8h26s10: return (const void *)classify_kernel<8, kFastCAP, false, 26, -10, 16, T>;
+    case kV8h26s7m18: return (const void *)classify_kernel<8, kFastCAP, false, 26, -7, 18, T>;
+    case kV8h26s8m18: return (const void *)classify_kernel<8, kFastCAP, false, 26, -8, 18, T>;
+    case kV8h26s10m18: return (const void *)classify_kernel<8, kFastCAP, false, 26, -10, 18, T>;
+    default: return (const void *)classify_kernel<kSlowR, kSlowCAP, true, 0, 0, 0>;   // the exact path reads tight rows byte by byte at run time
     }
 }
+
+// v in [0, kNVariants): rows as words; v + kNVariants: the same instantiation reading tight rows (host-fed door)
+const void *variant_fn(int v) { return v >= kNVariants ? variant_fn_t<true>(v - kNVariants) : variant_fn_t<false>(v); }
 
 struct OccKey { int dev, variant; size_t smem; };
 struct OccEnt { OccKey k; int blocks; };
 std::mutex g_occ_mu;
 std::vector<OccEnt> g_occ;
-std::atomic<bool> g_attr_done[64][kNVariants];   // hipFuncSetAttribute(160 KB of LDS) once per device and kernel (set from several host threads: cq_multi)
+std::atomic<bool> g_attr_done[64][2 * kNVariants];   // hipFuncSetAttribute(160 KB of LDS) once per device and kernel (set from several host threads: cq_multi)
 
 hipError_t ensure_lds_optin(int dev, int v)
 {
@@ -1132,16 +1174,18 @@ hipError_t fast_resident(int dev, int v, size_t sm, int &n)
     return hipSuccess;
 }
 
-template <int R, int H, int RL, int M>
-void launch_one(const DevIndex &ix, const QueryArgs &a, unsigned grid, size_t sm, hipStream_t stream)
+// every instantiation has the one signature (DevIndex, QueryArgs): launched through its pointer
+void launch_one(int variant, const DevIndex &ix, const QueryArgs &a, unsigned grid, size_t sm, hipStream_t stream)
 {
-    hipLaunchKernelGGL((classify_kernel<R, kFastCAP, false, H, RL, M>), dim3(grid), dim3(kBlock), sm, stream, ix, a);
+    DevIndex ixc = ix;
+    QueryArgs ac = a;
+    void *args[2] = {&ixc, &ac};
+    (void)hipLaunchKernel(variant_fn(variant), dim3(grid), dim3(kBlock), args, sm, stream);
 }
 
-// The fast kernel: persistent waves, each walking its own sub-tiles of R reads.
 hipError_t launch_fast(int variant, const DevIndex &ix, QueryArgs &a, int n_cus, int per_cu, hipStream_t stream)
 {
-    const int R = variant == kV4 ? 4 : 8;
+    const int R = (variant % kNVariants) == kV4 ? 4 : 8;
     const size_t sm = smem_bytes(R, kFastCAP, a, a.use_lds_hist);
     if (const char *v = getenv("CAMMIQ_BLOCKS_PER_CU")) per_cu = atoi(v);   // tuning knob
     if (per_cu < 1) per_cu = 1;
@@ -1154,37 +1198,26 @@ hipError_t launch_fast(int variant, const DevIndex &ix, QueryArgs &a, int n_cus,
     if (const char *v = getenv("CAMMIQ_MAX_SUB_PER_WAVE")) max_sub = (uint64_t)atoi(v) >= 1 && (uint64_t)atoi(v) < max_sub ? (uint64_t)atoi(v) : max_sub;   // test knob
     const uint64_t chunk = a.use_lds_hist ? grid_full * kWaves * max_sub * R : a.n_reads;
     const uint32_t *packed0 = a.packed;
+    const uint8_t *tight0 = a.tight;
     const uint8_t *lens0 = a.lens;
     const uint64_t n_total = a.n_reads;
     hipError_t e = hipSuccess;
     for (uint64_t c0 = 0; c0 < n_total; c0 += chunk) {
         a.read0 = c0;
         a.n_reads = n_total - c0 < chunk ? n_total - c0 : chunk;
-        a.packed = packed0 + c0 * a.stride_words;
+        a.packed = packed0 ? packed0 + c0 * a.stride_words : nullptr;
+        a.tight = tight0 ? tight0 + c0 * a.tight_sb : nullptr;
         a.lens = lens0 + c0;
         const uint64_t n_sub = (a.n_reads + R - 1) / R;
         uint64_t grid = grid_full;
         const uint64_t need = (n_sub + kWaves - 1) / kWaves;
         if (grid > need) grid = need;
         if (grid == 0) grid = 1;
-        switch (variant) {
-        case kV4: launch_one<4, 0, 0, 0>(ix, a, (unsigned)grid, sm, stream); break;
-        case kV8h26r100: launch_one<8, 26, 100, 16>(ix, a, (unsigned)grid, sm, stream); break;
-        case kV8h26r150: launch_one<8, 26, 150, 16>(ix, a, (unsigned)grid, sm, stream); break;
-        case kV8h26r100m18: launch_one<8, 26, 100, 18>(ix, a, (unsigned)grid, sm, stream); break;
-        case kV8h26r150m18: launch_one<8, 26, 150, 18>(ix, a, (unsigned)grid, sm, stream); break;
-        case kV8h26s7: launch_one<8, 26, -7, 16>(ix, a, (unsigned)grid, sm, stream); break;
-        case kV8h26s8: launch_one<8, 26, -8, 16>(ix, a, (unsigned)grid, sm, stream); break;
-        case kV8h26s10: launch_one<8, 26, -10, 16>(ix, a, (unsigned)grid, sm, stream); break;
-        case kV8h26s7m18: launch_one<8, 26, -7, 18>(ix, a, (unsigned)grid, sm, stream); break;
-        case kV8h26s8m18: launch_one<8, 26, -8, 18>(ix, a, (unsigned)grid, sm, stream); break;
-        case kV8h26s10m18: launch_one<8, 26, -10, 18>(ix, a, (unsigned)grid, sm, stream); break;
-        default: launch_one<8, 0, 0, 0>(ix, a, (unsigned)grid, sm, stream); break;
-        }
+        launch_one(variant, ix, a, (unsigned)grid, sm, stream);
         e = hipGetLastError();
         if (e != hipSuccess) break;
     }
-    a.read0 = 0; a.n_reads = n_total; a.packed = packed0; a.lens = lens0;
+    a.read0 = 0; a.n_reads = n_total; a.packed = packed0; a.tight = tight0; a.lens = lens0;
     return e;
 }
 
@@ -1215,6 +1248,7 @@ hipError_t launch_classify(const DevIndex &ix, QueryArgs a, int n_cus, hipStream
         (e = fast_resident(dev, kV4, smem_bytes(4, kFastCAP, a, false), r4)) != hipSuccess) return e;
     if (hist_ok && ((e = fast_resident(dev, kV8, smem_bytes(8, kFastCAP, a, true), r8h)) != hipSuccess ||
                     (e = fast_resident(dev, kV4, smem_bytes(4, kFastCAP, a, true), r4h)) != hipSuccess)) return e;
+    const int tv = a.tight ? kNVariants : 0;   // the instantiations that read tight rows
     int R = (r8 <= 3 && r4 > r8) ? 4 : 8;   // measured: four reads per sub-tile cost 14 % at equal residency and 8 % at 6 against 5 workgroups (150 bp), and win 13 % at 6 against 3 (250 bp)
     if (const char *v = getenv("CAMMIQ_FAST_R")) R = atoi(v) == 4 ? 4 : 8;   // tuning knob
     const int plain = R == 8 ? r8 : r4, with = R == 8 ? r8h : r4h;
@@ -1237,7 +1271,7 @@ hipError_t launch_classify(const DevIndex &ix, QueryArgs a, int n_cus, hipStream
         if (a.wmax == 150 - 26 + 1 && a.stride_words == 10) fx = m18 ? kV8h26r150m18 : kV8h26r150;
         if (fx >= 0) {
             int n = 0;   // same LDS layout as the generic kernel of this shape; its own register count
-            if ((e = fast_resident(dev, fx, smem_bytes(8, kFastCAP, a, a.use_lds_hist != 0), n)) != hipSuccess) return e;
+            if ((e = fast_resident(dev, fx + tv, smem_bytes(8, kFastCAP, a, a.use_lds_hist != 0), n)) != hipSuccess) return e;
             if (n >= per_cu) { variant = fx; per_cu = n; }
         }
     }
@@ -1249,7 +1283,13 @@ hipError_t launch_classify(const DevIndex &ix, QueryArgs a, int n_cus, hipStream
                 info->minimizer_len = (int)ix.minimizer_len;
                 info->blocks_per_cu = per_cu; }
     if (ev_start) { e = hipEventRecord(ev_start, stream); if (e != hipSuccess) return e; }
-    e = launch_fast(variant, ix, a, n_cus, per_cu, stream);
+    if (tv) {   // the tight build of the chosen instantiation has its own register count: ask once, keep what stays resident
+        int n = 0;
+        if ((e = fast_resident(dev, variant + tv, smem_bytes(R, kFastCAP, a, a.use_lds_hist != 0), n)) != hipSuccess) return e;
+        if (n < per_cu) per_cu = n;
+        if (info) info->blocks_per_cu = per_cu;
+    }
+    e = launch_fast(variant + tv, ix, a, n_cus, per_cu, stream);
     if (e != hipSuccess) return e;
     if (ev_mid) { e = hipEventRecord(ev_mid, stream); if (e != hipSuccess) return e; }
     // exact slow path for reads with more than kFastCAP hits (usually none: the kernel reads the count from

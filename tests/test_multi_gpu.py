@@ -131,6 +131,41 @@ def test_tight_rows_equal_ascii_reads(tmp_path, rl):
         assert e.value.code == -1
 
 
+@pytest.mark.parametrize("fused", ["1", "0"])
+def test_tight_rows_through_the_exact_slow_path_and_every_kernel_shape(tmp_path, monkeypatch, fused):
+    """The classify kernel's own staging widens tight rows (round 4; CAMMIQ_FUSED_WIDEN=0: the separate widening kernel of
+    rounds 2-3).  Every kernel shape that reads them: the exact slow path (dense markers: far more than 16 hits per read,
+    rows read byte by byte), h = 26 at 100 / 150 bp (shape folded in), 101 / 125 / 151 bp (stride folded in), the generic
+    kernel (another h; ragged lengths up to 255: strides that are not a multiple of four bytes, R = 4 for long reads)."""
+    monkeypatch.setenv("CAMMIQ_FUSED_WIDEN", fused)
+    gen = synth.clade_genomes(31, 1, 3, 1200, 0.05)
+    u, d = synth.select_markers(gen, 10, 16, keep_every=1, seed=0)
+    pu, pd = build_index(tmp_path, u, d, 8, name="dense")
+    reads = synth.simulate_reads(gen, 700, (60, 255), 0.005, 3)
+    b, o = synth.concat_reads(reads)
+    ix = cq.Index(pu, pd, device=0)
+    tight, lens, _ = cq.pack_reads_tight(b, o, 8)
+    ref = oracle_lib.OracleIndex(pu, pd).query(b, o, len(gen))
+    got = ix.query_packed_tight(tight, lens, 0, len(gen))
+    assert_same(got, ref, "dense markers through the tight door")
+    assert int(np.max(ref["rcount_u"])) > 0
+    gen = synth.clade_genomes(77, 3, 4, 4000, 0.03)
+    u, d = synth.select_markers(gen, 26, 48, keep_every=2, seed=6)
+    pu, pd = build_index(tmp_path, u, d, 26, name="h26")
+    ix = cq.Index(pu, pd, device=0)
+    oi = oracle_lib.OracleIndex(pu, pd)
+    for rl in (100, 150, 101, 125, 151, (26, 255), 250):
+        reads = synth.simulate_reads(gen, 9001, rl, 0.01, 4, frac_random=0.1)
+        b, o = synth.concat_reads(reads)
+        tight, lens, sk = cq.pack_reads_tight(b, o, 26)
+        assert sk == 0
+        for mode in (cq.MODE_P, cq.MODE_SC):
+            ref = oi.query(b, o, len(gen), mode=mode, nthreads=8)
+            got = ix.query_packed_tight(tight, lens, 0, len(gen), mode=mode)
+            assert_same(got, ref, f"tight door, rl={rl}, mode={mode}, fused={fused}", rcount=(mode == cq.MODE_P))
+            assert got["pairs"] == ref["pairs"]
+
+
 def test_large_rcount_comes_back_through_the_bounce_buffers(tmp_path):
     """rcount arrays in pageable memory take the pinned double-buffered D2H path: rcount_u here is larger
     than one 16 MiB bounce buffer (several pieces), rcount_d larger than the 1 MiB direct-copy limit."""
