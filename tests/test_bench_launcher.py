@@ -43,7 +43,7 @@ def test_configs4_sizing_rule():
     assert 1_000_000 < half < 3_450_000
     markers = 15_000 * half * configs4.MARKERS_PER_GENOME_BASE
     assert markers * configs4.BYTES_PER_MARKER_HOST_PEAK <= 0.72 * 100e9 * 1.001
-    tiny, _, _ = configs4.size_for_this_box(15_000, 3_450_000, host_budget_bytes=20e9, shm_bytes=400e9)
+    tiny, _, _ = configs4.size_for_this_box(15_000, 3_450_000, host_budget_bytes=10e9, shm_bytes=400e9)
     assert tiny < 400_000
 
 
