@@ -582,7 +582,7 @@ int upload(cq_index *ix)
         }
     }
     const size_t sb = img.table_words * sizeof(uint32_t);
-    CQ_HIP(hipMalloc((void **)&ix->d_ovf_count, sizeof(uint32_t)));
+    CQ_HIP(hipMalloc((void **)&ix->d_ovf_count, (size_t)(1 + cq::kWorkStripes) * cq::kWorkStripeWords * sizeof(uint32_t)));
     CQ_HIP(hipMalloc((void **)&ix->d_stamps, 8 * sizeof(uint64_t)));
     CQ_HIP(hipMemset(ix->d_stamps, 0, 8 * sizeof(uint64_t)));
     int rc = pairs_alloc(ix, pair_cap_from_env());
@@ -875,7 +875,8 @@ int query_device_impl(cq_index *ix, int mode, const uint32_t *d_packed, const ui
         return fail(CQ_ERR_RANGE, "index holds refID " + std::to_string(img.max_refid) + " > n_genomes");
     if (n_reads == 0) return CQ_OK;
     CQ_HIP(hipSetDevice(ix->device));
-    if (!*ovf.count) CQ_HIP(hipMalloc((void **)ovf.count, sizeof(uint32_t)));
+    if (!*ovf.count)   // [0] reads on the slow-path list; from word kWorkStripeWords on: the kernel's striped work counter
+        CQ_HIP(hipMalloc((void **)ovf.count, (size_t)(1 + cq::kWorkStripes) * cq::kWorkStripeWords * sizeof(uint32_t)));
     if (*ovf.cap < n_reads) {   // grow the slow-path list (outside steady state)
         CQ_HIP(hipDeviceSynchronize());   // an earlier launch may still be using the old list
         if (*ovf.list) CQ_HIP(hipFree(*ovf.list));
@@ -901,6 +902,8 @@ int query_device_impl(cq_index *ix, int mode, const uint32_t *d_packed, const ui
     a.rcount = (mode == CQ_MODE_P) ? d_rcount : nullptr;
     a.ovf_list = *ovf.list;
     a.ovf_count = *ovf.count;
+    // the tail of every launch's sub-tiles is handed out dynamically (CAMMIQ_DYNAMIC=0: stride only, A/B knob)
+    a.work_counter = (getenv("CAMMIQ_DYNAMIC") && atoi(getenv("CAMMIQ_DYNAMIC")) == 0) ? nullptr : *ovf.count + cq::kWorkStripeWords;
     a.ovf_cap = (uint32_t)*ovf.cap;
     a.pair_keys = ix->d_pair_keys;
     a.pair_cnts = ix->d_pair_cnts;

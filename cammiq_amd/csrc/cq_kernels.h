@@ -19,6 +19,8 @@ struct DevIndex {
     uint32_t minimizer_len;  // m of this index's table (cq_device.h: 16, or 18 for large tables)
 };
 
+constexpr uint32_t kWorkStripes = 64, kWorkStripeWords = 32;   // the kernel's work counter: 64 words, each in a 128-byte line of its own
+
 struct QueryArgs {
     const uint32_t *packed;  // n_reads rows of stride_words uint32 (null when `tight` is given)
     const uint8_t *tight;    // or: n_reads rows of tight_sb BYTES (cq_pack_reads_tight), widened by the kernel's staging itself;
@@ -40,6 +42,8 @@ struct QueryArgs {
     uint32_t *rcount;        // may be null
     uint32_t *ovf_list;      // reads whose hit list overflowed the fast path
     uint32_t *ovf_count;
+    uint32_t *work_counter;  // kWorkStripes x kWorkStripeWords device words (zeroed per launch by the launcher): the tail of the sub-tiles is handed out from here, one stripe per group of waves; null: stride only
+    uint32_t max_sub;        // sub-tiles one wave may take (LDS histogram; set by the launcher, 0: no bound)
     uint32_t ovf_cap;
     uint32_t use_lds_hist;
     uint64_t *pair_keys;     // SC mode pair map (power-of-two capacity)

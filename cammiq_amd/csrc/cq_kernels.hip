@@ -540,7 +540,30 @@ classify_kernel(DevIndex ix, QueryArgs a)
         }
         if (lane < nr) pf_len = a.lens[r0 + lane];
     };
-    if (!SLOW) prefetch(wave_gid);
+    // ---- which sub-tiles a wave takes.  Stride wave_gid, wave_gid + n_waves, ... for the first 7/8 of the rounds, then one
+    // at a time off a (striped) device counter (a.work_counter, zeroed per launch).  With the stride alone the kernel ends when its
+    // SLOWEST wave does: a wave's time is a sum of ~n_sub / n_waves sub-tile times that differ with the reads' hits, and the
+    // maximum over 6 144 waves of such sums lies several standard deviations above their mean -- measured: a 2 M-read launch
+    // (41 sub-tiles per wave) takes 0.897 ms where 1/25 of a 50 M-read launch (1 017 per wave) takes 0.818.  The tail off the
+    // counter evens the waves out.  max_sub (LDS histogram: 15-bit halves, launch_fast) still bounds what one wave takes.
+    // (32-bit arithmetic: n_reads < 2^31, so every sub-tile index fits; the wave's loop is short of scalar registers)
+    // The counter is STRIPED: kWorkStripes words, each in a cache line of its own; stripe g serves the waves with
+    // wave_gid % stripes == g and hands out the sub-tiles dyn_base + g, + stripes, + 2 stripes ...  (One counter for all
+    // 6 144 waves serialises on its address: the waves leave the static rounds together, 6 144 atomics on one line cost a
+    // 2 M-read launch 0.26 ms -- 1.10 against 0.84 ms.)
+    const bool dyn = !SLOW && a.work_counter != nullptr;
+    const uint32_t static_rounds = dyn ? ((uint32_t)n_sub / (uint32_t)n_waves) * 7u / 8u : 0u;
+    const uint32_t dyn_base = static_rounds * (uint32_t)n_waves;
+    const uint32_t stripes = (uint32_t)n_waves < kWorkStripes ? (uint32_t)n_waves : kWorkStripes;
+    const uint32_t stripe = (uint32_t)wave_gid % stripes;
+    auto grab = [&]() -> uint64_t {   // the next sub-tile of this wave's stripe (wave-uniform)
+        uint32_t k = 0;
+        if (lane == 0) k = atomicAdd(a.work_counter + stripe * kWorkStripeWords, 1u);
+        return (uint64_t)(dyn_base + stripe + stripes * (uint32_t)__builtin_amdgcn_readfirstlane(k));
+    };
+    uint64_t sub = (dyn && static_rounds == 0) ? grab() : wave_gid;
+    uint32_t rounds_done = 0;
+    if (!SLOW) prefetch(sub);
 #if CQ_STAMPS
     unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0}, st_last;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last) :: "memory");
@@ -548,7 +571,7 @@ classify_kernel(DevIndex ix, QueryArgs a)
     // clock (s_memrealtime) across this wave's whole main loop
     const unsigned long long ck_c0 = st_last, ck_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
-    for (uint64_t sub = wave_gid; sub < n_sub; sub += n_waves) {
+    while (sub < n_sub) {
         const uint64_t r0 = sub * R;
         const uint32_t nr = (uint32_t)((n_reads - r0) < (uint64_t)R ? (n_reads - r0) : (uint64_t)R);
 
@@ -604,7 +627,11 @@ classify_kernel(DevIndex ix, QueryArgs a)
             t.len[lane] = len;
             t.hitcnt[lane] = 0;
         }
-        if (!SLOW) prefetch(sub + n_waves);   // in flight while this sub-tile is processed
+        // the sub-tile after this one: by stride, or off the counter once the static rounds are through
+        rounds_done++;
+        uint64_t sub_next = sub + n_waves;
+        if (dyn && rounds_done >= static_rounds) sub_next = (a.max_sub && rounds_done >= a.max_sub) ? n_sub : grab();
+        if (!SLOW) prefetch(sub_next);   // in flight while this sub-tile is processed
         wave_sync();
         CQ_STAMP(0);   // staging
 
@@ -850,6 +877,7 @@ classify_kernel(DevIndex ix, QueryArgs a)
         }
         wave_sync();   // hit lists fully consumed before the next sub-tile resets them
         CQ_STAMP(4);   // decision
+        sub = sub_next;
     }
 #if CQ_STAMPS
     if (!SLOW && lane == 0 && a.stamps) {
@@ -1198,6 +1226,7 @@ hipError_t launch_fast(int variant, const DevIndex &ix, QueryArgs &a, int n_cus,
     if (const char *v = getenv("CAMMIQ_MAX_SUB_PER_WAVE")) max_sub = (uint64_t)atoi(v) >= 1 && (uint64_t)atoi(v) < max_sub ? (uint64_t)atoi(v) : max_sub;   // test knob
     const uint64_t chunk = a.use_lds_hist ? grid_full * kWaves * max_sub * R : a.n_reads;
     const uint32_t *packed0 = a.packed;
+    uint32_t *const work_counter0 = a.work_counter;
     const uint8_t *tight0 = a.tight;
     const uint8_t *lens0 = a.lens;
     const uint64_t n_total = a.n_reads;
@@ -1213,11 +1242,25 @@ hipError_t launch_fast(int variant, const DevIndex &ix, QueryArgs &a, int n_cus,
         const uint64_t need = (n_sub + kWaves - 1) / kWaves;
         if (grid > need) grid = need;
         if (grid == 0) grid = 1;
+        // the dynamic tail, unless the LDS histogram's bound on what ONE wave may take (max_sub) could leave a stripe's
+        // sub-tiles unfinished: every wave of a stripe can still take max_sub - static_rounds of them, so the stripe with the
+        // fewest waves must have room for the largest stripe's share (the kernel's arithmetic, repeated here).  configs[2]'s
+        // 50 M-read launch: 1 017 of 1 023 per wave, 889 by stride, 96 waves x 134 = 12 864 >= 12 313 per stripe: on.
+        a.max_sub = a.use_lds_hist ? (uint32_t)max_sub : 0u;
+        uint32_t *wc = work_counter0;
+        if (wc && a.use_lds_hist) {
+            const uint64_t n_waves = grid * kWaves, stripes = n_waves < kWorkStripes ? n_waves : kWorkStripes;
+            const uint64_t static_rounds = (n_sub / n_waves) * 7 / 8, n_dyn = n_sub - static_rounds * n_waves;
+            const uint64_t demand = (n_dyn + stripes - 1) / stripes, room = (n_waves / stripes) * (max_sub > static_rounds ? max_sub - static_rounds : 0);
+            if (room < demand) wc = nullptr;
+        }
+        a.work_counter = wc;
+        if (wc) { e = hipMemsetAsync(wc, 0, (size_t)kWorkStripes * kWorkStripeWords * sizeof(uint32_t), stream); if (e != hipSuccess) break; }
         launch_one(variant, ix, a, (unsigned)grid, sm, stream);
         e = hipGetLastError();
         if (e != hipSuccess) break;
     }
-    a.read0 = 0; a.n_reads = n_total; a.packed = packed0; a.tight = tight0; a.lens = lens0;
+    a.read0 = 0; a.n_reads = n_total; a.packed = packed0; a.tight = tight0; a.lens = lens0; a.work_counter = work_counter0;
     return e;
 }
 

@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ap = argparse.ArgumentParser()
 ap.add_argument("--config", default="1")
 ap.add_argument("--steps", default="10")
-ap.add_argument("--extra", default="", help="extra bench.py arguments, one string")
+ap.add_argument("--extra", default="", help="extra bench.py arguments, one string (write --extra=\"--flag ...\" when it starts with a dash)")
 ap.add_argument("--timeout", type=float, default=600.0,
                 help="seconds per variant; the bench child runs in its own session and its whole group is killed")
 ap.add_argument("names", nargs="+")

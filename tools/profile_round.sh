@@ -29,15 +29,16 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --output-format csv -d "$out/pmc_$c" -- python3 "$root/bench.py" "$@" --steps 3 --warmup 1 --no-cpu-baseline --no-host-fed > "$out/bench_$c.json" 2> "$out/pmc_$c.err"
 done
 python3 - "$out" <<'PY'
-import csv,glob,json,sys,collections
+import csv,glob,json,sys,collections,re,os
 out=sys.argv[1]; res={}
+FAST=re.compile(r"classify_kernel(<\d+, \d+, false|ILi\d+ELi\d+ELb0E)")   # demangled or mangled: classify_kernel<R, CAP, SLOW = false, ...>
 line=json.loads(open(out+"/bench_under_rocprof.json").read().strip().splitlines()[-1])
 cfg=line["config"]
 for c in ("FETCH_SIZE","WRITE_SIZE"):
     d=collections.defaultdict(float)
-    for f in glob.glob(f"{out}/pmc_{c}/**/*counter_collection.csv",recursive=True):
+    for f in sorted(glob.glob(f"{out}/pmc_{c}/**/*counter_collection.csv",recursive=True), key=os.path.getmtime)[-1:]:   # this pass's file (a merged local copy may hold older ones)
         for r in csv.DictReader(open(f)):
-            if r["Counter_Name"]==c and "classify_kernel" in r["Kernel_Name"] and ("Lb0" in r["Kernel_Name"] or "false" in r["Kernel_Name"]):   # the fast classify kernel only (round 4: layout and calibration kernels also carry a `false`)
+            if r["Counter_Name"]==c and FAST.search(r["Kernel_Name"]):   # the fast classify kernel only (SLOW = false: the third template argument)
                 d[r["Dispatch_Id"]]+=float(r["Counter_Value"])
     v=list(d.values())
     res[c+"_KB_per_launch"]=sum(v)/len(v); res[c+"_launches"]=len(v)
@@ -52,9 +53,8 @@ res["workload_key"]=cfg["workload_key"]; res["table_GB"]=cfg["table_GB"]
 res["kernel_ms_under_stats"]=line["roofline"]["kernel_ms"]
 res["kernel"]=line["roofline"].get("kernel")
 # the --stats mean of the fast classify kernel itself (what a reader recomputes the fraction from)
-import os
 for r in csv.DictReader(open(out+"/kernel_stats.csv")):
-    if "classify_kernel" in r["Name"] and ("Lb0" in r["Name"] or "false" in r["Name"]):
+    if FAST.search(r["Name"]):
         res["kernel_ms_rocprof_stats"]=float(r["AverageNs"])/1e6; res["rocprof_stats_calls"]=int(r["Calls"]); res["rocprof_stats_name"]=r["Name"]
 up=out+"/bench_unprofiled.json"
 if os.path.exists(up):
