@@ -19,6 +19,7 @@ struct DevIndex {
     uint32_t minimizer_len;  // m of this index's table (cq_device.h: 16, or 18 for large tables)
 };
 
+constexpr uint32_t kStaticSixteenths = 12;   // 3/4 by stride, the last quarter off the counter (8 / 12 / 14 / 15 sixteenths: equal on a 50 M-read launch, 12 and 8 1.6-1.9 % ahead of 14 on 10 M- and 2 M-read launches; profiles/r04_dynamic_tail_static_share.txt)
 constexpr uint32_t kWorkStripes = 64, kWorkStripeWords = 32;   // the kernel's work counter: 64 words, each in a 128-byte line of its own
 
 struct QueryArgs {
@@ -44,6 +45,7 @@ struct QueryArgs {
     uint32_t *ovf_count;
     uint32_t *work_counter;  // kWorkStripes x kWorkStripeWords device words (zeroed per launch by the launcher): the tail of the sub-tiles is handed out from here, one stripe per group of waves; null: stride only
     uint32_t max_sub;        // sub-tiles one wave may take (LDS histogram; set by the launcher, 0: no bound)
+    uint32_t static_16ths;   // sixteenths of a wave's share it takes by stride before it turns to the counter (set by the launcher)
     uint32_t ovf_cap;
     uint32_t use_lds_hist;
     uint64_t *pair_keys;     // SC mode pair map (power-of-two capacity)

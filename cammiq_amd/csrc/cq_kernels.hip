@@ -540,7 +540,7 @@ classify_kernel(DevIndex ix, QueryArgs a)
         }
         if (lane < nr) pf_len = a.lens[r0 + lane];
     };
-    // ---- which sub-tiles a wave takes.  Stride wave_gid, wave_gid + n_waves, ... for the first 7/8 of the rounds, then one
+    // ---- which sub-tiles a wave takes.  Stride wave_gid, wave_gid + n_waves, ... for the first 3/4 of the rounds, then one
     // at a time off a (striped) device counter (a.work_counter, zeroed per launch).  With the stride alone the kernel ends when its
     // SLOWEST wave does: a wave's time is a sum of ~n_sub / n_waves sub-tile times that differ with the reads' hits, and the
     // maximum over 6 144 waves of such sums lies several standard deviations above their mean -- measured: a 2 M-read launch
@@ -552,7 +552,7 @@ classify_kernel(DevIndex ix, QueryArgs a)
     // 6 144 waves serialises on its address: the waves leave the static rounds together, 6 144 atomics on one line cost a
     // 2 M-read launch 0.26 ms -- 1.10 against 0.84 ms.)
     const bool dyn = !SLOW && a.work_counter != nullptr;
-    const uint32_t static_rounds = dyn ? ((uint32_t)n_sub / (uint32_t)n_waves) * 7u / 8u : 0u;
+    const uint32_t static_rounds = dyn ? ((uint32_t)n_sub / (uint32_t)n_waves) * a.static_16ths / 16u : 0u;
     const uint32_t dyn_base = static_rounds * (uint32_t)n_waves;
     const uint32_t stripes = (uint32_t)n_waves < kWorkStripes ? (uint32_t)n_waves : kWorkStripes;
     const uint32_t stripe = (uint32_t)wave_gid % stripes;
@@ -1245,12 +1245,14 @@ hipError_t launch_fast(int variant, const DevIndex &ix, QueryArgs &a, int n_cus,
         // the dynamic tail, unless the LDS histogram's bound on what ONE wave may take (max_sub) could leave a stripe's
         // sub-tiles unfinished: every wave of a stripe can still take max_sub - static_rounds of them, so the stripe with the
         // fewest waves must have room for the largest stripe's share (the kernel's arithmetic, repeated here).  configs[2]'s
-        // 50 M-read launch: 1 017 of 1 023 per wave, 889 by stride, 96 waves x 134 = 12 864 >= 12 313 per stripe: on.
+        // 50 M-read launch: 1 017 of 1 023 per wave, 762 by stride, 96 waves x 261 = 25 056 >= 24 504 per stripe: on.
         a.max_sub = a.use_lds_hist ? (uint32_t)max_sub : 0u;
+        a.static_16ths = kStaticSixteenths;
+        if (const char *v = getenv("CAMMIQ_STATIC_16THS")) a.static_16ths = (uint32_t)std::min(16, std::max(0, atoi(v)));   // tuning knob
         uint32_t *wc = work_counter0;
         if (wc && a.use_lds_hist) {
             const uint64_t n_waves = grid * kWaves, stripes = n_waves < kWorkStripes ? n_waves : kWorkStripes;
-            const uint64_t static_rounds = (n_sub / n_waves) * 7 / 8, n_dyn = n_sub - static_rounds * n_waves;
+            const uint64_t static_rounds = (n_sub / n_waves) * a.static_16ths / 16, n_dyn = n_sub - static_rounds * n_waves;
             const uint64_t demand = (n_dyn + stripes - 1) / stripes, room = (n_waves / stripes) * (max_sub > static_rounds ? max_sub - static_rounds : 0);
             if (room < demand) wc = nullptr;
         }
