@@ -143,13 +143,20 @@ bool prescan(const uint8_t *ap, size_t nbits, size_t aux_start, const uint8_t *i
     uint64_t nb = 0, nl = 0, nn = 0;
     marks.clear();
     for (;;) {
+        if (nb % step == 0) marks.push_back(Mark{aux.pos, nb, nl, nn});
+        // "1 0000": the root is a leaf (93 % of the buckets).  It cannot be the terminator -- that is a run of one-bits --
+        // so the byte stream is not looked at: the scan of a 15 GB table touches its 0.8 GB of shape bits only.  (A byte
+        // stream that disagrees -- END64 or another impossible key inside a chunk, too few bytes -- is rejected by
+        // decode_chunk's own checks and by the bounds test at the end, and the file goes to the serial decoder.)
+        if (aux.peek5() == 0x10u) { aux.pos += 5; nb++; nl++; continue; }
         const uint64_t ipos = 8 * nb + rec * nl;
         if (ipos + 8 > in) return false;
         uint64_t hv = 0;
         for (int k = 0; k < 8; k++) hv = (hv << 8) | ip[ipos + k];
-        if (nb % step == 0 || hv == CQ_EMPTY_KEY) marks.push_back(Mark{aux.pos, nb, nl, nn});
-        if (hv == CQ_EMPTY_KEY) return true;
-        if (aux.peek5() == 0x10u) { aux.pos += 5; nb++; nl++; continue; }   // "1 0000": the root is a leaf
+        if (hv == CQ_EMPTY_KEY) {
+            if (marks.empty() || marks.back().buckets != nb) marks.push_back(Mark{aux.pos, nb, nl, nn});
+            return true;   // every byte position before this one is smaller: the chunks stay inside the byte stream
+        }
         if (aux.pos + 5 > nbits) return false;
         if (aux.bit() != 1u) return false;
         // depth bookkeeping: slots[d] = child slots of the open node at depth d still to be read
