@@ -14,7 +14,10 @@ communicator that cannot be set up ends the run with a non-zero status.
 
 Workload at N = 1 = BASELINE.json configs[2] (the configuration north_star quotes the metric on):
 1000 synthetic bacterial-size genomes, --both index (unique + doubly-unique markers, h = k = 26),
-50 M x 100 bp reads per step.  `--config 1` runs configs[1] (500 genomes, --unique, 10 M reads).
+50 M x 100 bp reads per step.  `--config 1` runs configs[1] (500 genomes, --unique, 10 M reads);
+`--config 4` configs[4]'s per-GPU shard: ~15 000 genomes x 3.45 Mbp --both (1.26e9 markers, 92 GB on the device --
+or what this box's host can build: the line says which), 125 M x 150 bp reads per step, one resident batch, the
+CPU leg and the parity gate on a slice against the generator's sub-index.
 N > 1 is weak scaling (configs[3] shape): the index is replicated and every rank classifies its own
 50 M reads per step.
 
@@ -29,8 +32,10 @@ i.e. with everything the host hands to the ILP (query.cpp:251-258).  Index load 
 parsing are outside, exactly like the reference's own `Time for query` (query.cpp:459,645-647).
 
 `value` counts reads with the inputs resident in HBM when the clock starts.  The PCIe-inclusive
-rate of the same workload -- packed reads in pinned HOST memory, pipelined H2D + kernels + D2H
-through cq_query_packed, SURVEY.md 8(d)'s bracket -- is reported next to it as `host_fed`.
+rate of the same workload -- tight 2-bit rows in pinned HOST memory, pipelined H2D + kernels,
+counters and rcount back in the caller's arrays through cq_query_packed_tight: SURVEY.md 8(d)'s
+bracket -- is reported next to it as `host_fed` / `value_survey_8d_bracket`.  `roofline.board`
+says what THIS board's memory system gives (cq_calibrate, ~0.15 s before the timed region).
 Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations

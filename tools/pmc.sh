@@ -8,14 +8,15 @@ tag=$1; shift
 out=$root/gpurun_out/pmc_$tag
 rm -rf "$out"; mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --pmc "$@" --output-format csv -d "$out" -- python3 "$root/bench.py" ${BENCH_ARGS:-} --steps 2 --warmup 1 --no-cpu-baseline --no-host-fed > "$out/bench.json" 2> "$out/err.log" || { rc=$?; echo "pass $tag ($*) FAILED rc=$rc; last lines of err.log:"; tail -40 "$out/err.log"; exit $rc; }
+rocprofv3 --pmc "$@" --output-format csv -d "$out" -- python3 "$root/bench.py" ${BENCH_ARGS:-} --steps 2 --warmup 1 --no-cpu-baseline --no-host-fed --no-calibrate > "$out/bench.json" 2> "$out/err.log" || { rc=$?; echo "pass $tag ($*) FAILED rc=$rc; last lines of err.log:"; tail -40 "$out/err.log"; exit $rc; }
 python3 - "$out" <<'PY'
-import csv,glob,sys,collections
+import csv,glob,sys,collections,re
 out=sys.argv[1]
+FAST=re.compile(r"classify_kernel(<\d+, \d+, false|ILi\d+ELi\d+ELb0E)")   # the fast classify kernel: SLOW = false is its third template argument
 acc=collections.defaultdict(list)
 for f in glob.glob(out+"/**/*counter_collection.csv",recursive=True):
     for r in csv.DictReader(open(f)):
-        if "Lb0" in r["Kernel_Name"] or "false" in r["Kernel_Name"]:
+        if FAST.search(r["Kernel_Name"]):
             acc[r["Counter_Name"]].append((r["Dispatch_Id"],float(r["Counter_Value"])))
 for k,v in sorted(acc.items()):
     d=collections.defaultdict(float)
