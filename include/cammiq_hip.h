@@ -142,7 +142,9 @@ typedef struct cq_counts {
     uint64_t *cnt_u;     /* [n_genomes+1]  Genome::read_cnts_u (query.hpp:15), index 0 unused */
     uint64_t *cnt_d;     /* [n_genomes+1]  Genome::read_cnts_d (query.hpp:16) */
     uint32_t *rcount_u;  /* [n_leaves[U]]  pleafNode::rcount, decode order; may be NULL in SC mode */
-    uint32_t *rcount_d;  /* [n_leaves[D]] */
+    uint32_t *rcount_d;  /* [n_leaves[D]]  (both are written in full by every CQ_MODE_P query.  Over the link they travel
+                            as one byte per leaf + an escape list and are widened into these arrays by the library's own
+                            threads -- bit-exact; page-locked arrays from cq_host_alloc and plain arrays both work) */
     uint64_t nundet;     /* FqReader::nundet (query.hpp:43) */
     uint64_t nconf;      /* FqReader::nconf  (query.hpp:40) */
     uint64_t nskipped;   /* reads outside the parity domain (len < h, len > 255, non-ACGT byte):
@@ -210,8 +212,9 @@ int cq_pack_read(const uint8_t *seq, uint32_t len, uint32_t hash_len, uint32_t s
  * 100-bp read instead of 28 -- for reads that have to cross the host link (H2D is what bounds a host-fed
  * query: 57 GB/s against 2.2 G reads/s of kernel).  Base j of a read goes to byte j/4, bits
  * [7-2(j%4) : 6-2(j%4)]; row r starts at packed + r * stride_bytes, no alignment.  cq_query_packed_tight copies
- * the tight rows to the GPU and widens them there to the word rows the kernels take (one small kernel per
- * chunk); everything else is cq_query_packed.  A length above 4 * stride_bytes is CQ_ERR_ARG.
+ * the tight rows to the GPU, where the classify kernel's own staging widens them (no second copy of the rows in
+ * HBM; rounds 2-3 ran a small widening kernel per chunk); lengths of a chunk whose reads all have one length are
+ * not sent at all; everything else is cq_query_packed.  A length above 4 * stride_bytes is CQ_ERR_ARG.
  */
 uint32_t cq_pack_stride_bytes(uint32_t max_len);
 int cq_pack_reads_tight(const uint8_t *bases, const uint64_t *offsets, uint64_t n_reads,
