@@ -343,7 +343,9 @@ def main():
                     cqdist.allreduce_counts(hc, hr if nleaf else None)
                     ctr.copy_(hc); rcd.copy_(hr)
             h_ctr.copy_(ctr, non_blocking=True)
-            h_rc.copy_(rcd, non_blocking=True)                         # rcount once per query (pinned: link speed)
+            if nleaf:                                                  # rcount once per query: the library's narrow way back
+                rc_host = h_rc.numpy().view(np.uint32)                 # (cq_rcount_fetch: a byte per leaf + escapes over the link,
+                ix.rcount_fetch(rcd.data_ptr(), stream, rc_host[:nu], rc_host[nu:nu + nd])   # widened into these pinned arrays)
 
         def fence():
             if world > 1:
@@ -479,7 +481,7 @@ def main():
                            "table_buckets_overflowed": info["n_overflowed"], "table_max_chain": info["max_chain"],
                            "bracket": "K x (classify kernels + D2H of the counter block)"
                                       + (", RCCL all-reduce of counts + rcount" if world > 1 else "")
-                                      + ", D2H of rcount (pinned) once; inputs resident in HBM",
+                                      + ", rcount back in pinned host arrays once (cq_rcount_fetch); inputs resident in HBM",
                            "parallelism": f"reads sharded x{world}, index replicated"
                                           + (f"; exchange step: {reduce_how}" if world > 1 else "")},
                 "roofline": roof,

@@ -91,6 +91,7 @@ SIGNATURES = {
     "cq_multi_query_packed_tight": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32,
                                               C.c_uint32, C.c_uint32, C.POINTER(_Counts)]),
     "cq_calibrate": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "cq_rcount_fetch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "cq_host_alloc": (C.c_int, [C.POINTER(C.c_void_p), C.c_size_t]),
     "cq_host_free": (None, [C.c_void_p]),
     "cq_pairs_reserve": (C.c_int, [C.c_void_p, C.c_uint64]),
@@ -308,6 +309,13 @@ class Index:
                                      sw, max_len, n_genomes, C.c_void_p(d_counters_ptr),
                                      C.c_void_p(d_rcount_ptr) if d_rcount_ptr else None,
                                      C.c_void_p(stream_ptr) if stream_ptr else None))
+
+    def rcount_fetch(self, d_rcount_ptr: int, stream_ptr: int | None, rcount_u: np.ndarray, rcount_d: np.ndarray):
+        """cq_rcount_fetch: a device rcount array (raw pointer) -> the two host uint32 arrays, narrow over the link."""
+        assert rcount_u.dtype == np.uint32 and rcount_d.dtype == np.uint32
+        assert len(rcount_u) == self.n_leaves[0] and len(rcount_d) == self.n_leaves[1]
+        _check(lib().cq_rcount_fetch(self._h, C.c_void_p(d_rcount_ptr), C.c_void_p(stream_ptr) if stream_ptr else None,
+                                     _p(rcount_u) if rcount_u.size else None, _p(rcount_d) if rcount_d.size else None))
 
     def last_kernel_ms(self) -> float:
         ms = C.c_float(0)

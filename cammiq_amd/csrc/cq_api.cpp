@@ -1209,7 +1209,7 @@ int query_checks(const cq_index *ix, int mode, uint32_t n_genomes, const cq_coun
     return CQ_OK;
 }
 
-int narrow_start(cq_index *ix, uint64_t n_u, uint64_t n_d, uint32_t *dst_u, uint32_t *dst_d);   // below (rcount's narrow way back)
+int narrow_start(cq_index *ix, uint64_t n_u, uint64_t n_d, uint32_t *dst_u, uint32_t *dst_d, const uint32_t *src = nullptr);   // below (rcount's narrow way back)
 
 // Classify reads [lo, hi) of `f` on ix's device into the handle's own counter block (d_ctr) and
 // rcount array (d_rc), both zeroed first: resetCounters + query64_* (query.cpp:1820-1840, 458-1080).
@@ -1556,9 +1556,10 @@ int ensure_narrow(cq_index *ix, uint64_t nl)
 // What a query hands the ILP is unchanged: uint32 per leaf in decode order (query.cpp:1161,1176-1177).
 // narrow_start queues the kernel on s_comp (behind whatever is queued there) and wakes the pool; narrow_finish waits for the
 // threads and writes the escapes.  Not started (no pool, too few leaves): narrow_inflight stays false, the caller copies.
-int narrow_start(cq_index *ix, uint64_t n_u, uint64_t n_d, uint32_t *dst_u, uint32_t *dst_d)
+int narrow_start(cq_index *ix, uint64_t n_u, uint64_t n_d, uint32_t *dst_u, uint32_t *dst_d, const uint32_t *src)
 {
     const uint64_t nl = n_u + n_d;
+    if (!src) src = ix->d_rc;   // the handle's own array (host-fed doors), or the caller's (cq_rcount_fetch)
     ix->narrow_inflight = false;
     int rc = ensure_narrow(ix, nl);
     if (rc != CQ_OK) return rc;
@@ -1574,7 +1575,7 @@ int narrow_start(cq_index *ix, uint64_t n_u, uint64_t n_d, uint32_t *dst_u, uint
     const uint32_t epoch = ix->narrow_epoch;
     CQ_HIP(hipMemsetAsync(ix->d_esc_count, 0, sizeof(uint32_t), ix->s_comp));
     if (tr) tr->dev("narrow_begin", 0, ix->s_comp);
-    CQ_HIP(cq::launch_narrow_rcount(ix->d_rc, nl, ix->h_narrow, seg, ix->h_flags, epoch, ix->d_esc, ix->d_esc_count, ix->esc_cap, ix->d_blocks_done,
+    CQ_HIP(cq::launch_narrow_rcount(src, nl, ix->h_narrow, seg, ix->h_flags, epoch, ix->d_esc, ix->d_esc_count, ix->esc_cap, ix->d_blocks_done,
                                     ix->h_esc_count, ix->s_comp));
     CQ_HIP(hipEventRecord(ix->ev_narrow, ix->s_comp));
     if (tr) tr->dev("narrow_end", 0, ix->s_comp);
@@ -1745,6 +1746,35 @@ int cq_query_packed_tight(cq_index *ix, int mode, const uint8_t *packed, const u
     f.sw = (stride_bytes + 3) / 4;
     f.max_len = max_len;
     return query_one(ix, mode, f, n_reads, n_genomes, out);
+}
+
+int cq_rcount_fetch(cq_index *ix, const uint32_t *d_rcount, void *stream, uint32_t *rcount_u, uint32_t *rcount_d)
+{
+    if (!ix || !d_rcount) return fail(CQ_ERR_ARG, "cq_rcount_fetch: NULL argument");
+    if (ix->device < 0) return fail(CQ_ERR_NO_DEVICE, "index was loaded host-only");
+    const cq::FlatImage &img = ix->H->img;
+    const uint64_t n_u = img.n_leaves[0], n_d = img.n_leaves[1];
+    if ((n_u && !rcount_u) || (n_d && !rcount_d)) return fail(CQ_ERR_ARG, "cq_rcount_fetch: rcount_u / rcount_d must be provided");
+    if (n_u + n_d == 0) return CQ_OK;
+    if ((uintptr_t)d_rcount & 15u) return fail(CQ_ERR_ARG, "cq_rcount_fetch: d_rcount must be 16-byte aligned");
+    CQ_HIP(hipSetDevice(ix->device));
+    if (!ix->s_comp) CQ_HIP(hipStreamCreateWithFlags(&ix->s_comp, hipStreamNonBlocking));
+    if (!ix->ev_zeroed) CQ_HIP(hipEventCreateWithFlags(&ix->ev_zeroed, hipEventDisableTiming));
+    // the narrow kernel runs on the handle's compute queue, behind everything queued on the caller's stream so far
+    CQ_HIP(hipEventRecord(ix->ev_zeroed, (hipStream_t)stream));
+    CQ_HIP(hipStreamWaitEvent(ix->s_comp, ix->ev_zeroed, 0));
+    int rc = narrow_start(ix, n_u, n_d, rcount_u, rcount_d, d_rcount);
+    if (rc != CQ_OK) return rc;
+    bool plain = true;
+    rc = narrow_finish(ix, n_u, rcount_u, rcount_d, &plain);
+    if (rc != CQ_OK) return rc;
+    if (plain) {   // few leaves, no worker threads, or more saturated leaves than the escape list holds: the plain uint32 copy
+        CQ_HIP(hipStreamSynchronize((hipStream_t)stream));
+        if (!ix->s_copy) CQ_HIP(hipStreamCreateWithFlags(&ix->s_copy, hipStreamNonBlocking));
+        rc = copy_out(ix, rcount_u, d_rcount, n_u * 4);
+        if (rc == CQ_OK) rc = copy_out(ix, rcount_d, d_rcount + n_u, n_d * 4);
+    }
+    return rc;
 }
 
 /* ------------------------------------------------------------------------------------------

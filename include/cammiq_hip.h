@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define CQ_ABI_VERSION 5   /* 5: cq_calibrate; 4: cq_last_launch_info; every host-fed SC-mode query starts from an empty pair map */
+#define CQ_ABI_VERSION 5   /* 5: cq_calibrate, cq_rcount_fetch; 4: cq_last_launch_info; every host-fed SC-mode query starts from an empty pair map */
 
 /*
  * Design limits of one handle (= one GPU's replica of the index).  The reference's pointer trie has none beyond its
@@ -282,6 +282,17 @@ typedef struct cq_launch_info {
     int32_t minimizer_len;    /* m of the index (16 / 18): part of the instantiation's name when fixed_shape */
 } cq_launch_info;
 int cq_last_launch_info(cq_index *idx, cq_launch_info *out);
+
+/*
+ * The device door's way back for rcount: d_rcount (n_leaves[U] + n_leaves[D] uint32 in HBM, U first, 16-byte aligned --
+ * what cq_query_device accumulated into, after cq_counts_allreduce where several GPUs take part) -> the caller's two
+ * host arrays, the reference's pleafNode::rcount per leaf in decode order (hashtrie.hpp:43; read by the ILP,
+ * query.cpp:1161,1176-1177).  Ordered behind everything queued on `stream`; synchronous: returns with the arrays
+ * filled.  The transport is the host-fed doors': one byte per leaf + an escape list written by a kernel straight into
+ * page-locked memory, widened by the library's threads while it arrives (a quarter of a plain uint32 copy's time on
+ * the link); plain arrays and cq_host_alloc'ed ones both work.
+ */
+int cq_rcount_fetch(cq_index *idx, const uint32_t *d_rcount, void *stream, uint32_t *rcount_u, uint32_t *rcount_d);
 
 /*
  * Diagnostic, no reference analogue: what THIS board gives the classify kernel to work with, measured in about a

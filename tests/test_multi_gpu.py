@@ -227,6 +227,42 @@ def test_rcount_comes_back_narrow_and_exact(tmp_path, monkeypatch, how):
     assert_same(m.query_packed_tight(tight, tl, 100, G), ref, f"{how}: two shards")
 
 
+@pytest.mark.parametrize("narrow_from", ["1", None])
+def test_rcount_fetch_brings_a_device_array_back(tmp_path, monkeypatch, narrow_from):
+    """cq_rcount_fetch: the device door's way back for rcount (what cq_query_device accumulated into) -- narrow over the
+    link when the index has enough leaves (forced here by CAMMIQ_NARROW_FROM=1), the plain copy otherwise; into
+    page-locked and into plain arrays; ordered behind the caller's stream."""
+    import torch
+    from cammiq_amd import bigsynth
+    if narrow_from:
+        monkeypatch.setenv("CAMMIQ_NARROW_FROM", narrow_from)
+        monkeypatch.setenv("CAMMIQ_NARROW_SEG", "8192")
+    G = 60
+    w = bigsynth.World(seed=21, n_genomes=G, genome_len=300_000, pair_share=0.3)
+    pu, pd = str(tmp_path / "index_u.bin1"), str(tmp_path / "index_d.bin2")
+    nu, nd = w.write_index(pu, pd)
+    b, o = w.reads(seed=6, n=40_000, length=100)
+    hot = np.repeat(b.reshape(-1, 100)[:20], 400, axis=0)       # leaves past 255: the escape list
+    b = np.ascontiguousarray(np.concatenate([b.reshape(-1, 100), hot]).ravel())
+    n = 40_000 + 8_000
+    o = np.arange(n + 1, dtype=np.uint64) * np.uint64(100)
+    ref = oracle_lib.OracleIndex(pu, pd).query(b, o, G, nthreads=8)
+    ix = cq.Index(pu, pd, device=0)
+    packed, lens, _ = cq.pack_reads(b, o, 26)
+    dp = torch.from_numpy(packed.view(np.int32)).cuda()
+    dl = torch.from_numpy(lens).cuda()
+    ctr = torch.zeros(ix.counter_words(G), dtype=torch.int64, device="cuda")
+    rc = torch.zeros(nu + nd, dtype=torch.int32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    ix.query_device(cq.MODE_P, dp.data_ptr(), dl.data_ptr(), n, packed.shape[1], 100, G, ctr.data_ptr(), rc.data_ptr(), st)
+    for pinned in (True, False):
+        ru = cq.host_array(nu, np.uint32) if pinned else np.full(nu, 0xABABABAB, np.uint32)
+        rd = cq.host_array(nd, np.uint32) if pinned else np.full(nd, 0xABABABAB, np.uint32)
+        ix.rcount_fetch(rc.data_ptr(), st, ru, rd)              # queued behind the classify kernels on `st`
+        assert np.array_equal(ru, ref["rcount_u"]) and np.array_equal(rd, ref["rcount_d"]), f"pinned={pinned}"
+    assert int(ref["rcount_u"].max()) >= 400
+
+
 def test_pair_map_grows_instead_of_failing(tmp_path, monkeypatch):
     """query64_sc's read_cnts_b with more distinct pairs than the device map has slots: the library
     grows the map and classifies again (it used to return CQ_ERR_LIMIT); output arrays that are too
