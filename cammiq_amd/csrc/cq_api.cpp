@@ -108,7 +108,7 @@ void widen_span(const uint8_t *src8, uint64_t a, uint64_t b, uint64_t n_u, uint3
 }
 
 // A few host threads that sleep between queries and widen the segments of one narrow rcount as the GPU delivers them
-// (fetch_rcount_narrow).  flags[s] == epoch: segment s is in `narrow`; the threads take segments off a shared counter.
+// (narrow_start / narrow_finish).  flags[s] == epoch: segment s is in `narrow`; the threads take segments off a shared counter.
 struct WidenPool {
     std::vector<std::thread> th;
     std::mutex mu;
@@ -285,7 +285,7 @@ struct cq_index {
     uint32_t *d_rc = nullptr; size_t rc_cap = 0;
     void *h_bounce[2] = {nullptr, nullptr};
     hipEvent_t ev_bounce[2] = {nullptr, nullptr};
-    // rcount's narrow way back (fetch_rcount_narrow)
+    // rcount's narrow way back (narrow_start / narrow_finish)
     uint8_t *d_rc8 = nullptr; size_t rc8_cap = 0;
     uint2 *d_esc = nullptr; uint32_t *d_esc_count = nullptr; uint32_t esc_cap = 0;
     uint8_t *h_narrow = nullptr; size_t narrow_cap = 0;   // page-locked: the kernel writes rcount's bytes here

@@ -83,7 +83,7 @@ hipError_t launch_widen_rows(const uint8_t *tight, uint32_t sb, uint32_t *rows, 
 // MEMORY (host_out8: n bytes), + an escape list of (leaf, count) for the entries of 255 and more (device; *esc_count counts
 // them all, esc holds the first esc_cap).  host_flags[s] = epoch once segment s (kNarrowSeg entries) is on the host;
 // host_flags[n_segments] = epoch and *host_esc_count = the number of escapes once all of them are.  blocks_done: a device
-// word, zero between calls.  rc must be 16-byte aligned (cq_api.cpp fetch_rcount_narrow).
+// word, zero between calls.  rc must be 16-byte aligned (cq_api.cpp narrow_start).
 constexpr uint64_t kNarrowSeg = 1ull << 16;
 hipError_t launch_narrow_rcount(const uint32_t *rc, uint64_t n, uint8_t *host_out8, uint64_t seg, uint32_t *host_flags, uint32_t epoch, uint2 *esc,
                                 uint32_t *esc_count, uint32_t esc_cap, uint32_t *blocks_done, uint32_t *host_esc_count, hipStream_t stream);

@@ -187,7 +187,7 @@ def test_large_rcount_comes_back_through_the_bounce_buffers(tmp_path):
 @pytest.mark.parametrize("how", ["ring", "escapes_overrun", "off"])
 def test_rcount_comes_back_narrow_and_exact(tmp_path, monkeypatch, how):
     """rcount crosses the link as one byte per leaf + an escape list for counts of 255 and more and is widened into the
-    caller's uint32 arrays by the library (cq_api.cpp fetch_rcount_narrow): bit-exact with the oracle with leaves forced far
+    caller's uint32 arrays by the library (cq_api.cpp narrow_start): bit-exact with the oracle with leaves forced far
     past 255 (every read of a block repeated 700 times), through many small segments (each written to page-locked host memory and flagged by its own
     workgroup, one straddling the u / d boundary), into pinned and into pageable arrays, for every host-fed door; when
     the escape list overruns (forced: 3 entries) the plain uint32 copy takes over, silently and exactly."""

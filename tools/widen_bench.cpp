@@ -1,4 +1,4 @@
-// tools/widen_bench.cpp -- what the host gives rcount's narrow way back (cq_api.cpp fetch_rcount_narrow): bytes -> uint32
+// tools/widen_bench.cpp -- what the host gives rcount's narrow way back (cq_api.cpp narrow_start): bytes -> uint32
 // with streaming stores, T threads on disjoint ranges of an 84 M-entry array (configs[2]'s leaf count), into plain and into
 // page-locked memory is the same DRAM; GB/s WRITTEN.  The link delivers the bytes at ~55 GB/s, so the widening keeps up
 // from ~220 GB/s written on.     g++ -O2 -o tools/widen_bench tools/widen_bench.cpp -lpthread
