@@ -266,7 +266,7 @@ struct cq_index {
     hipEvent_t ev0 = nullptr, ev_mid = nullptr, ev1 = nullptr;   // start | fast kernel done | slow kernel done
     bool ev_valid = false;
     cq::LaunchInfo last_launch{};   // what launch_classify chose for the most recent launch (cq_last_launch_info)
-    // host-fed paths (cq_query, cq_query_packed): three staging slots so that packing chunk c+1 on
+    // host-fed paths (cq_query, cq_query_packed): staging slots (kSlots) so that packing chunk c+1 on
     // the CPU, its H2D copy and the classify kernel of chunk c overlap with slack for host jitter
     struct Slot {
         uint32_t *h_packed = nullptr, *d_packed = nullptr;   // pinned host / device rows
