@@ -29,6 +29,7 @@
 #include <cstring>
 #include <string>
 #include <thread>
+#include <sys/stat.h>
 #include <vector>
 
 #include "cq_index.hpp"
@@ -636,6 +637,42 @@ int prepare_host(const char *path_u, const char *path_d, double budget, std::sha
     // The reference loads the two files on two pthreads (query.cpp:112-116); same here.
     int rc_u = CQ_OK, rc_d = CQ_OK;
     std::string err_u, err_d;
+    // The table's block of HBM is asked for on a thread of its own (hipMalloc of 80 GB takes ~2 s, and every other
+    // allocation of the load queues behind it in the driver): before the decode, from the FILE SIZES -- a bucket whose root
+    // is a leaf takes 8 + 6 (unique) or 8 + 12 (doubly unique) bytes of the byte stream, any other bucket more, so
+    // size / 14 + size / 20 bounds the number of keys from above -- so that the block is there when the layout wants it.
+    // A block more than a tenth too large (an index of deep tries) is given back after the decode and asked for again.
+    auto start_prealloc = [&](uint64_t n_table_buckets) {
+        HostIndex *hp = H.get();
+        hp->prealloc_device = device;
+        hp->prealloc_buckets = n_table_buckets;
+        hp->prealloc_thread = std::thread([hp] {
+            if (hipSetDevice(hp->prealloc_device) != hipSuccess || hipMalloc(&hp->prealloc, hp->prealloc_buckets * 64) != hipSuccess) {
+                (void)hipGetLastError();
+                hp->prealloc = nullptr;
+            }
+        });
+    };
+    auto table_buckets_for = [&](double keys, double &kpb) {
+        // Average keys per 4-slot bucket of the device table.  Emptier tables overflow less
+        // (fewer windows take the exact path): 1.0 costs 64 B of HBM per key (measured: 0.5 -> +2 %,
+        // 1.5 -> -3 %); when the table would not fit comfortably it is packed tighter.
+        // CAMMIQ_KEYS_PER_BUCKET overrides (tuning knob, not part of the ABI).
+        kpb = 1.0;
+        if (keys / kpb * 64.0 > budget) kpb = std::min(3.2, keys * 64.0 / budget);
+        if (kpb_override > 0.0) kpb = kpb_override;
+        uint64_t nbk = (uint64_t)(keys / kpb) + 1;   // the hash range cq::prepare_image will choose ...
+        if (nbk < 16) nbk = 16;
+        return nbk + CQ_SPILL_TAIL;                  // ... + the spill tail
+    };
+    if (!from_cache && for_device && !stamped) {
+        struct stat su, sd;
+        double est = 0.0;
+        if (stat(path_u, &su) == 0) est += (double)su.st_size / 14.0;
+        if (have_d && stat(path_d, &sd) == 0) est += (double)sd.st_size / 20.0;
+        double kpb_est;
+        if (est >= 1e7 && gpu_layout_mode((uint64_t)est)) try { start_prealloc(table_buckets_for(est, kpb_est)); } catch (...) {}
+    }
     if (!from_cache) try {
         std::thread td;
         if (have_d) td = std::thread([&] { rc_d = cq::decode_table(path_d, H->tab[1], err_d); });
@@ -646,33 +683,22 @@ int prepare_host(const char *path_u, const char *path_d, double budget, std::sha
         if (!have_d) cq::make_empty_table(H->tab[0].hash_len, H->tab[1]);
         lt.lap("decode");
         std::string err;
-        // Average keys per 4-slot bucket of the device table.  Emptier tables overflow less
-        // (fewer windows take the exact path): 1.0 costs 64 B of HBM per key (measured: 0.5 -> +2 %,
-        // 1.5 -> -3 %); when the table would not fit comfortably it is packed tighter.
-        // CAMMIQ_KEYS_PER_BUCKET overrides (tuning knob, not part of the ABI).
         double kpb = 1.0;
         const double keys = (double)(H->tab[0].bucket_key.size() + H->tab[1].bucket_key.size());
-        if (keys / kpb * 64.0 > budget) kpb = std::min(3.2, keys * 64.0 / budget);
-        if (kpb_override > 0.0) kpb = kpb_override;
+        const uint64_t n_table_buckets = table_buckets_for(keys, kpb);
         const uint32_t m_len = m_override ? cq_minimizer_len(H->tab[0].hash_len, std::min<uint32_t>(m_override, CQ_MAX_MINIMIZER)) : 0u;
         // a handle on a GPU has its table laid out THERE (upload(): cq_layout_gpu.hip); the image cache and handles without
         // a device need the host builder's image
         H->gpu_layout = (for_device && !stamped) ? gpu_layout_mode((uint64_t)keys) : 0;
-        if (H->gpu_layout && keys >= 1e7) {
-            // the table's size is known now (the hash range cq::prepare_image will choose, + the spill tail): allocate it
-            // beside the host part of the layout
-            uint64_t nbk = (uint64_t)(keys / kpb) + 1;
-            if (nbk < 16) nbk = 16;
-            HostIndex *hp = H.get();
-            hp->prealloc_device = device;
-            hp->prealloc_buckets = nbk + CQ_SPILL_TAIL;
-            hp->prealloc_thread = std::thread([hp] {
-                if (hipSetDevice(hp->prealloc_device) != hipSuccess || hipMalloc(&hp->prealloc, hp->prealloc_buckets * 64) != hipSuccess) {
-                    (void)hipGetLastError();
-                    hp->prealloc = nullptr;
-                }
-            });
+        if (H->prealloc_thread.joinable() &&
+            (!H->gpu_layout || H->prealloc_buckets < n_table_buckets || (double)H->prealloc_buckets > 1.1 * (double)n_table_buckets)) {
+            // the estimate from the file sizes does not serve (host layout after all, or too small, or a tenth too large)
+            H->prealloc_thread.join();
+            if (H->prealloc) { (void)hipSetDevice(device); (void)hipFree(H->prealloc); H->prealloc = nullptr; }
+            H->prealloc_buckets = 0;
         }
+        // the table's size is known now: allocate it beside the host part of the layout, unless it is on its way already
+        if (H->gpu_layout && keys >= 1e7 && !H->prealloc_thread.joinable()) start_prealloc(n_table_buckets);
         int rc = H->gpu_layout ? cq::prepare_image(H->tab[0], H->tab[1], kpb, m_len, H->img, H->vals, err)
                                : cq::build_image(H->tab[0], H->tab[1], kpb, m_len, H->img, err);
         if (rc != CQ_OK) return fail(rc, err);
@@ -1180,6 +1206,7 @@ void warm_workspace(cq_index *ix, LoadTimer *lt)
     if (nl && !ix->d_rc && hipMalloc((void **)&ix->d_rc, nl * 4) == hipSuccess) ix->rc_cap = nl;
     if (!ix->d_ctr && hipMalloc((void **)&ix->d_ctr, cw * 8) == hipSuccess) ix->ctr_cap = cw;
     if (!ix->d_ovf_list && hipMalloc((void **)&ix->d_ovf_list, kChunk * sizeof(uint32_t)) == hipSuccess) ix->ovf_cap = kChunk;
+    lap("  rcount, counters");
     (void)ensure_narrow(ix, nl);
     lap("  narrow rcount path");
     (void)hipGetLastError();

@@ -18,6 +18,8 @@
 // order, one root code per bucket and 16-byte array-trie nodes for the (rare) deep keys.
 #include <algorithm>
 #include <atomic>
+#include <chrono>
+#include <climits>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -128,7 +130,9 @@ namespace {
 // shapes of all tries before it, and where it starts in the byte stream on the number of leaves before it.  A
 // first pass over the bit stream alone finds that out -- it walks the shapes without building anything (a '1'
 // followed by '0000' is a leaf, any other '1' opens four child slots) and notes, every `step` buckets, the bit
-// position and the bucket / leaf / node counts so far.  The chunks between two notes are then decoded by all cores
+// position and the bucket / leaf / node counts so far (prescan: the serial form, kept for CAMMIQ_DECODE_STEP and for
+// byte streams the parallel form's counts do not explain; parallel_scan below: the same notes from a prefix sum and a
+// prefix minimum over segments of the stream, on all cores).  The chunks between two notes are then decoded by all cores
 // at once, each writing straight into its slice of the final arrays (whose exact sizes the first pass also gave):
 // ids are global from the start, nothing is relocated or copied.  The scan accepts exactly the well-formed
 // streams; anything else (truncation, a bucket without a root, a key longer than 255, a bad leaf record) sends the
@@ -182,6 +186,136 @@ bool prescan(const uint8_t *ap, size_t nbits, size_t aux_start, const uint8_t *i
     }
 }
 
+// ---- the shape scan on all cores ----------------------------------------------------------------------------------
+// Every bit of the shape stream is one "child present?" answer of a pre-order walk; reading a bit b changes the number
+// of answers still owed by 4b - 1 (a present node owes four more, every answer settles one), and a bucket's trie is
+// complete when the count, started at 1, reaches 0.  So with S(p) = sum of (4b - 1) over the first p bits, bucket k ends
+// at the first p with S(p) = -k: the bucket boundaries are exactly the positions where S reaches a NEW MINIMUM -- a
+// prefix sum and a prefix minimum, both of which split over segments of the stream.  Leaves and inner nodes need no
+// context either: a leaf is a 1 followed by 0000 wherever it stands (every 1 in the stream is a node, the four bits
+// after a node are its children), an inner node any other 1.  This holds for ANY bit string, well formed or not: a walk
+// that starts at a boundary (decode_chunk) ends its buckets where S says and meets the leaves and nodes counted here,
+// so the chunks stay inside their slices of the output whatever the file holds; what the walk itself rejects (a bucket
+// whose first bit is 0, a key past 255, a bad record) and a byte stream whose END64 is not where the counts put it send
+// the file to the serial decoder, as before.
+struct ScanTables {
+    int8_t sum[256], minp[256];   // of one byte, MSB first: S after it, lowest S inside it (relative to S before it)
+    uint8_t ones[256];
+    uint8_t leaves[4096];         // leaves ("10000") that START in a byte, by the byte and the four bits after it
+    ScanTables()
+    {
+        for (int b = 0; b < 256; b++) {
+            int r = 0, mn = 127, o = 0;
+            for (int i = 7; i >= 0; i--) { const int bit = (b >> i) & 1; r += 4 * bit - 1; mn = std::min(mn, r); o += bit; }
+            sum[b] = (int8_t)r; minp[b] = (int8_t)mn; ones[b] = (uint8_t)o;
+        }
+        for (int w = 0; w < 4096; w++) {
+            int n = 0;
+            for (int j = 0; j < 8; j++) n += ((w >> (7 - j)) & 31) == 16;   // bits j .. j+4 of the 12-bit window
+            leaves[w] = (uint8_t)n;
+        }
+    }
+};
+const ScanTables kScan;
+
+struct SegStat { int64_t sum = 0, minp = 0; uint64_t ones = 0, leaves = 0; };
+
+// Byte i of the stream and the four bits after it (bits past the end read as 1, as everywhere).
+inline uint32_t window12(const uint8_t *ap, size_t nbytes, size_t i)
+{
+    return ((uint32_t)ap[i] << 4) | (i + 1 < nbytes ? (uint32_t)(ap[i + 1] >> 4) : 15u);
+}
+
+// The boundaries inside bytes [b0, b1), S = s before byte b0, lowest S so far = lo, ones / leaves before b0 given:
+// the FIRST one (last == false) or the LAST one.  Returns false when there is none.
+bool find_boundary(const uint8_t *ap, size_t nbytes, size_t b0, size_t b1, int64_t s, int64_t lo, uint64_t ones, uint64_t leaves,
+                   bool last, Mark &out)
+{
+    bool found = false;
+    for (size_t i = b0; i < b1; i++) {
+        const uint32_t b = ap[i];
+        if (s + kScan.minp[b] < lo) {   // a new minimum inside this byte: bit by bit
+            const uint32_t w = window12(ap, nbytes, i);
+            uint64_t o = ones, l = leaves;
+            int64_t r = s;
+            for (int j = 0; j < 8; j++) {
+                const uint32_t bit = (b >> (7 - j)) & 1u;
+                o += bit;
+                l += ((w >> (7 - j)) & 31u) == 16u;
+                r += 4 * (int64_t)bit - 1;
+                if (r < lo) {
+                    lo = r;
+                    out = Mark{8 * i + (size_t)j + 1, (uint64_t)(-r), l, o - l};
+                    found = true;
+                    if (!last) return true;
+                }
+            }
+        }
+        s += kScan.sum[b];
+        ones += kScan.ones[b];
+        leaves += kScan.leaves[window12(ap, nbytes, i)];
+    }
+    return found;
+}
+
+// marks: the start of the stream, one boundary per segment that has one, the end of the last bucket.
+bool parallel_scan(const uint8_t *ap, size_t nbytes, size_t start_byte, unsigned nt, size_t seg_bytes, std::vector<Mark> &marks)
+{
+    marks.clear();
+    marks.push_back(Mark{8 * start_byte, 0, 0, 0});
+    if (nbytes <= start_byte) return true;
+    const size_t nseg = (nbytes - start_byte + seg_bytes - 1) / seg_bytes;
+    std::vector<SegStat> st(nseg);
+    auto seg_lo = [&](size_t k) { return start_byte + k * seg_bytes; };
+    auto seg_hi = [&](size_t k) { return std::min(nbytes, start_byte + (k + 1) * seg_bytes); };
+    auto on_all = [&](size_t n, auto &&fn) {
+        std::atomic<size_t> next{0};
+        std::vector<std::thread> th;
+        const unsigned workers = (unsigned)std::min<size_t>(nt, n);
+        for (unsigned t = 1; t < workers; t++) th.emplace_back([&] { for (size_t k; (k = next.fetch_add(1)) < n;) fn(k); });
+        for (size_t k; (k = next.fetch_add(1)) < n;) fn(k);
+        for (auto &x : th) x.join();
+    };
+    on_all(nseg, [&](size_t k) {
+        SegStat a;
+        int64_t s = 0, mn = INT64_MAX;
+        for (size_t i = seg_lo(k), e = seg_hi(k); i < e; i++) {
+            const uint32_t b = ap[i];
+            mn = std::min(mn, s + kScan.minp[b]);
+            s += kScan.sum[b];
+            a.ones += kScan.ones[b];
+            a.leaves += kScan.leaves[window12(ap, nbytes, i)];
+        }
+        a.sum = s; a.minp = mn;
+        st[k] = a;
+    });
+    // prefix over the segments: S, lowest S, ones, leaves before each
+    std::vector<int64_t> s0(nseg), lo0(nseg);
+    std::vector<uint64_t> ones0(nseg), leaves0(nseg);
+    std::vector<size_t> with;   // segments that hold a boundary
+    {
+        int64_t s = 0, lo = 0;
+        uint64_t o = 0, l = 0;
+        for (size_t k = 0; k < nseg; k++) {
+            s0[k] = s; lo0[k] = lo; ones0[k] = o; leaves0[k] = l;
+            if (s + st[k].minp < lo) { with.push_back(k); lo = s + st[k].minp; }
+            s += st[k].sum; o += st[k].ones; l += st[k].leaves;
+        }
+    }
+    if (with.empty()) return true;   // no bucket at all
+    std::vector<Mark> first(with.size());
+    on_all(with.size(), [&](size_t j) {
+        const size_t k = with[j];
+        (void)find_boundary(ap, nbytes, seg_lo(k), seg_hi(k), s0[k], lo0[k], ones0[k], leaves0[k], false, first[j]);
+    });
+    for (const Mark &m : first) marks.push_back(m);
+    Mark end{};
+    const size_t k = with.back();
+    if (!find_boundary(ap, nbytes, seg_lo(k), seg_hi(k), s0[k], lo0[k], ones0[k], leaves0[k], true, end)) return false;
+    if (end.aux_pos != marks.back().aux_pos) marks.push_back(end);
+    return true;
+}
+
 }  // namespace
 
 static int decode_serial(const std::string &path, DecodedTable &out, std::string &err);
@@ -226,7 +360,7 @@ static bool decode_chunk(const uint8_t *ap, size_t nbits, const uint8_t *ip, siz
             out.bucket_code[b] = CQ_LEAF_BIT | (uint32_t)(nl - 1);
             continue;
         }
-        (void)aux.bit();   // the root's '1'; not a leaf (that was the fast path), so an inner node
+        if (aux.bit() != 1u) return false;   // a bucket without a root node; otherwise not a leaf (that was the fast path): an inner node
         stack.clear();
         nodes[nn] = Node{{0, 0, 0, 0}};
         const uint32_t root_code = (uint32_t)nn;
@@ -240,6 +374,7 @@ static bool decode_chunk(const uint8_t *ap, size_t nbits, const uint8_t *ip, siz
             if (!aux.bit()) continue;
             const size_t q = aux.pos;
             const uint32_t w = ((uint32_t)ap[q >> 3] << 8) | ((q >> 3) + 1 < ((nbits + 7) >> 3) ? ap[(q >> 3) + 1] : 0xFFu);
+            if (h + stack.size() > 255) return false;   // a key longer than 255
             if (((w >> (12 - (q & 7))) & 15u) == 0) {
                 aux.pos += 4;
                 if (!read_leaf((uint32_t)stack.size())) return false;
@@ -266,16 +401,37 @@ int decode_table(const std::string &path, DecodedTable &out, std::string &err)
     if (tenv) nt = (unsigned)std::max(1, atoi(tenv));
     Mapped fi, fa;
     const bool opened = nt > 1 && fi.open(path) && fa.open(path + ".aux");
-    if (opened && fa.n >= 2 && (getenv("CAMMIQ_DECODE_STEP") || fi.n >= (64u << 20))) {
+    if (opened && fa.n >= 2 && (getenv("CAMMIQ_DECODE_STEP") || getenv("CAMMIQ_DECODE_SEG") || fi.n >= (64u << 20))) {
         const uint32_t doubly = fa.p[0] >> 7, option = fa.p[0] & 127u, h = fa.p[1];
         if (option == 64 && h >= 1 && h <= 31) {
             const size_t rec = doubly ? 12 : 6;
             uint64_t step = std::max<uint64_t>(1, fi.n / (8 + rec) / ((uint64_t)nt * 8));
             if (const char *v = getenv("CAMMIQ_DECODE_STEP")) step = (uint64_t)std::max(1, atoi(v));
             std::vector<Mark> marks;
-            if (prescan(fa.p, fa.n * 8, 16, fi.p, fi.n, rec, h, step, marks) && marks.back().leaves < 0x7FFFFFFFull &&
+            const bool timing = getenv("CAMMIQ_LOAD_TIMING") != nullptr;
+            const auto t0 = std::chrono::steady_clock::now();
+            auto lap = [&](const char *what) {
+                if (timing) fprintf(stderr, "[decode_table]   %-8s %-18s %8.1f ms\n", doubly ? "(d)" : "(u)", what,
+                                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+            };
+            // the scan: on all cores (parallel_scan; CAMMIQ_DECODE_SEG = bytes per segment, tests), or -- CAMMIQ_DECODE_STEP set,
+            // or a byte stream that does not end where the parallel scan's counts put its END64 -- the serial walk
+            bool scanned = false;
+            if (!getenv("CAMMIQ_DECODE_STEP")) {
+                size_t seg = std::max<size_t>(4096, (fa.n + (size_t)nt * 16 - 1) / ((size_t)nt * 16));
+                if (const char *v = getenv("CAMMIQ_DECODE_SEG")) seg = (size_t)std::max(1, atoi(v));
+                if (parallel_scan(fa.p, fa.n, 2, nt, seg, marks)) {
+                    const Mark &e = marks.back();
+                    const uint64_t ipos = 8 * e.buckets + rec * e.leaves;
+                    uint64_t hv = 0;
+                    if (ipos + 8 <= fi.n) for (int k = 0; k < 8; k++) hv = (hv << 8) | fi.p[ipos + k];
+                    scanned = ipos + 8 <= fi.n && hv == CQ_EMPTY_KEY;
+                }
+            }
+            if ((scanned || prescan(fa.p, fa.n * 8, 16, fi.p, fi.n, rec, h, step, marks)) && marks.back().leaves < 0x7FFFFFFFull &&
                 marks.back().nodes + 1 < 0x7FFFFFFFull) {
                 const Mark &end = marks.back();
+                lap(scanned ? "scan (all cores) at" : "scan (serial) at");
                 out = DecodedTable();
                 out.doubly = doubly;
                 out.hash_len = h;
@@ -303,6 +459,7 @@ int decode_table(const std::string &path, DecodedTable &out, std::string &err)
                         });
                     for (auto &x : th) x.join();
                 }
+                lap("chunks done at");
                 if (!bad.load()) return CQ_OK;
             }
         }

@@ -165,8 +165,28 @@ std::unique_ptr<Entry[]> sort_entries(std::unique_ptr<Entry[]> &e, size_t n, uin
 // the 4-children form.  find64_p's semantics carry over: inner chain nodes are never leaves
 // (keys are prefix-free and leaves have no children), so "consume len matching symbols or fail"
 // is exactly what the symbol-by-symbol walk does.
+// The two tables' tries seen as ONE node array without building it: indices 1 .. nnu are ht_u's nodes as decoded, nnu + 1 ..
+// nnu + nnd ht_d's with their references moved into the common id space (d nodes after u nodes, d leaves after u leaves).
+struct LinkedTries {
+    const Node *u, *d;        // decoded node arrays (index 0 = dummy)
+    uint32_t nnu, leaf_off;
+    uint32_t relink_d(uint32_t code) const
+    {
+        if (code == 0) return 0;
+        if (code & CQ_LEAF_BIT) return CQ_LEAF_BIT | ((code & ~CQ_LEAF_BIT) + leaf_off);
+        return code + nnu;
+    }
+    Node operator[](uint32_t i) const
+    {
+        if (i <= nnu) return u[i];
+        Node n = d[i - nnu];
+        for (int c = 0; c < 4; c++) n.child[c] = relink_d(n.child[c]);
+        return n;
+    }
+};
+
 struct Compressor {
-    const std::vector<Node> &in;
+    const LinkedTries &in;
     std::vector<Node> &out;
     const uint32_t *r1, *r2;   // refIDs by global leaf id: a chain that ends at a unique leaf carries the refID inline
     uint32_t run(uint32_t code)
@@ -255,20 +275,9 @@ int prepare_image(const DecodedTable &u, const DecodedTable &d, double keys_per_
     // ---- link the two tries into one node array; give leaves global ids (u first)
     const uint64_t nnu = u.nodes.size() - 1, nnd = d.nodes.size() - 1;  // real nodes (index 0 = dummy)
     if (nnu + nnd + 1 >= 0x7FFFFFFFull) { err = "more than 2^31-1 trie nodes in total"; return CQ_ERR_LIMIT; }
-    std::vector<Node> linked(1 + nnu + nnd);
-    linked[0] = Node{{0, 0, 0, 0}};
-    for (uint64_t i = 1; i <= nnu; i++) linked[i] = u.nodes[i];  // u codes are already global
-    const uint32_t node_off = (uint32_t)nnu, leaf_off = (uint32_t)nu;
-    auto relink_d = [&](uint32_t code) -> uint32_t {
-        if (code == 0) return 0;
-        if (code & CQ_LEAF_BIT) return CQ_LEAF_BIT | ((code & ~CQ_LEAF_BIT) + leaf_off);
-        return code + node_off;
-    };
-    for (uint64_t i = 1; i <= nnd; i++) {
-        Node n = d.nodes[i];
-        for (int c = 0; c < 4; c++) n.child[c] = relink_d(n.child[c]);
-        linked[nnu + i] = n;
-    }
+    // (no linked copy of the node arrays: at configs[4]'s size they are 13 GB, and the only reader is the path compression)
+    const LinkedTries linked{u.nodes.data(), d.nodes.data(), (uint32_t)nnu, (uint32_t)nu};
+    auto relink_d = [&](uint32_t code) { return linked.relink_d(code); };
     // the device gets the path-compressed form (bucket roots are compressed where they are used)
     img.nodes.clear();
     img.nodes.push_back(Node{{0, 0, 0, 0}});

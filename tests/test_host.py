@@ -224,16 +224,21 @@ def test_packer_fuzz_all_byte_values():
     assert sk == nbad
 
 
-@pytest.mark.parametrize("decoder", ["serial", "parallel"])
+@pytest.mark.parametrize("decoder", ["serial", "parallel", "scan"])
 def test_loader_survives_corrupted_files(tmp_path, monkeypatch, decoder):
     """Bit flips, truncations and garbage must come back as status codes (the reference asserts
     or walks off its buffers); a file that still loads must decode like the oracle does.  Both
     decoders: the chunked one (scan + parallel chunks) hands every stream its scan does not accept to the
     serial one, so the two must agree on what loads and on the status of what does not."""
     import random
-    if decoder == "parallel":
+    monkeypatch.delenv("CAMMIQ_DECODE_STEP", raising=False)
+    monkeypatch.delenv("CAMMIQ_DECODE_SEG", raising=False)
+    if decoder == "parallel":     # serial shape scan, chunks of 5 buckets
         monkeypatch.setenv("CAMMIQ_DECODE_THREADS", "4")
         monkeypatch.setenv("CAMMIQ_DECODE_STEP", "5")
+    elif decoder == "scan":       # the shape scan on all cores (prefix sum + prefix minimum), segments of 3 bytes
+        monkeypatch.setenv("CAMMIQ_DECODE_THREADS", "4")
+        monkeypatch.setenv("CAMMIQ_DECODE_SEG", "3")
     else:
         monkeypatch.setenv("CAMMIQ_DECODE_THREADS", "1")
     gen = synth.clade_genomes(3, 1, 3, 800, 0.05)
@@ -268,8 +273,9 @@ def test_loader_survives_corrupted_files(tmp_path, monkeypatch, decoder):
         open(victim, "wb").write(good[victim])
     assert failed > 20 and loaded + failed == 120
     _CORRUPTION_OUTCOMES[decoder] = outcome
-    if len(_CORRUPTION_OUTCOMES) == 2:
-        assert _CORRUPTION_OUTCOMES["serial"] == _CORRUPTION_OUTCOMES["parallel"]
+    for other in ("parallel", "scan"):
+        if "serial" in _CORRUPTION_OUTCOMES and other in _CORRUPTION_OUTCOMES:
+            assert _CORRUPTION_OUTCOMES["serial"] == _CORRUPTION_OUTCOMES[other], other
 
 
 _CORRUPTION_OUTCOMES = {}
@@ -284,8 +290,10 @@ def test_chunked_decoder_equals_serial_decoder(name, tmp_path, monkeypatch):
     g = golden(name)
     monkeypatch.setenv("CAMMIQ_IMAGE_CACHE", "1")
     images = []
-    for threads, step in (("1", None), ("2", "1"), ("5", "7"), ("8", "1000"), ("3", "100000000")):
-        d = tmp_path / f"t{threads}_s{step}"
+    # step: buckets per chunk after the serial shape scan; "seg N": the shape scan on all cores, N bytes per segment
+    for threads, step in (("1", None), ("2", "1"), ("5", "7"), ("8", "1000"), ("3", "100000000"),
+                          ("4", "seg 1"), ("3", "seg 2"), ("8", "seg 7"), ("2", "seg 4096")):
+        d = tmp_path / f"t{threads}_s{step}".replace(" ", "_")
         d.mkdir()
         pu = str(d / "index_u.bin1")
         pd = str(d / "index_d.bin2") if g["pd"] else None
@@ -294,10 +302,12 @@ def test_chunked_decoder_equals_serial_decoder(name, tmp_path, monkeypatch):
                 shutil.copy2(src, dst)
                 shutil.copy2(src + ".aux", dst + ".aux")
         monkeypatch.setenv("CAMMIQ_DECODE_THREADS", threads)
-        if step:
+        monkeypatch.delenv("CAMMIQ_DECODE_STEP", raising=False)
+        monkeypatch.delenv("CAMMIQ_DECODE_SEG", raising=False)
+        if step and step.startswith("seg "):
+            monkeypatch.setenv("CAMMIQ_DECODE_SEG", step[4:])
+        elif step:
             monkeypatch.setenv("CAMMIQ_DECODE_STEP", step)
-        else:
-            monkeypatch.delenv("CAMMIQ_DECODE_STEP", raising=False)
         ix = cq.Index(pu, pd, device=-1)
         images.append((ix.info_dict(), open(pu + ".cqimg", "rb").read()))
     for other in images[1:]:

@@ -25,7 +25,8 @@ def driver(tmp_path_factory):
 
 
 DECODERS = {"serial": {"CAMMIQ_DECODE_THREADS": "1"},
-            "chunked": {"CAMMIQ_DECODE_THREADS": "4", "CAMMIQ_DECODE_STEP": "3"}}   # scan + parallel chunks of 3 buckets
+            "chunked": {"CAMMIQ_DECODE_THREADS": "4", "CAMMIQ_DECODE_STEP": "3"},   # serial shape scan + parallel chunks of 3 buckets
+            "scan": {"CAMMIQ_DECODE_THREADS": "4", "CAMMIQ_DECODE_SEG": "2"}}       # shape scan on all cores, segments of 2 bytes
 
 
 def _run(driver, pu, pd, reads, decoder="serial"):
@@ -68,5 +69,5 @@ def test_corrupted_indices_under_asan_ubsan(driver, tmp_path):
             assert r.returncode == 0, (trial, f, decoder, r.stdout, r.stderr[-2000:])
             assert "AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-2000:]
             outs.append(r.stdout)
-        assert outs[0] == outs[1], "the chunked decoder and the serial one disagree on a corrupted file"
+        assert outs[0] == outs[1] == outs[2], "the chunked decoders and the serial one disagree on a corrupted file"
         (tmp_path / f).write_bytes(good[f])
