@@ -68,6 +68,8 @@ SIGNATURES = {
     "cq_index_free": (None, [C.c_void_p]),
     "cq_query": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32,
                            C.POINTER(_Counts)]),
+    "cq_query_reads": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32,
+                                 C.POINTER(_Counts)]),
     "cq_pack_stride_words": (C.c_uint32, [C.c_uint32]),
     "cq_pack_reads": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p,
                                 C.c_void_p, C.POINTER(C.c_uint64)]),
@@ -101,6 +103,8 @@ SIGNATURES = {
     "cq_multi_index": (C.c_void_p, [C.c_void_p, C.c_int]),
     "cq_multi_query": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32,
                                  C.POINTER(_Counts)]),
+    "cq_multi_query_reads": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32,
+                                       C.POINTER(_Counts)]),
     "cq_multi_query_packed": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32,
                                         C.c_uint32, C.c_uint32, C.POINTER(_Counts)]),
     "cq_multi_free": (None, [C.c_void_p]),
@@ -127,6 +131,8 @@ def lib():
             raise CammiqError(-100, f"{p} not built: run `python -c 'import __graft_entry__ as g; g.build()'`")
         L = C.CDLL(p)
         for name, (res, args) in SIGNATURES.items():
+            if not hasattr(L, name) and os.environ.get("CAMMIQ_LIB"):
+                continue   # an older experiment build named by CAMMIQ_LIB (tools/kexp.py A/B): calling the entry raises
             f = getattr(L, name)
             f.restype = res
             f.argtypes = args
@@ -266,13 +272,22 @@ class Index:
         return cu.value, cd.value, ch.value
 
     def query(self, bases: np.ndarray, offsets: np.ndarray, n_genomes: int, mode: int = MODE_P,
-              pair_cap: int = 1 << 16):
+              pair_cap: int = 1 << 16, out: "_CountsOut | None" = None):
         """One call of query64_p/_mt_p (MODE_P) or query64_sc (MODE_SC) on host ASCII reads."""
         bases = np.ascontiguousarray(bases, np.uint8)
         offsets = np.ascontiguousarray(offsets, np.uint64)
         n = len(offsets) - 1
-        o = _CountsOut(n_genomes, self.n_leaves, pair_cap)
+        o = out or _CountsOut(n_genomes, self.n_leaves, pair_cap)
         _check(lib().cq_query(self._h, mode, _p(bases), _p(offsets), n, n_genomes, C.byref(o.c)))
+        return o.result()
+
+    def query_reads(self, read_ptrs: np.ndarray, rlengths: np.ndarray, n_genomes: int, mode: int = MODE_P,
+                    pair_cap: int = 1 << 16, out: "_CountsOut | None" = None):
+        """cq_query_reads: the reference's own arrays -- one address per read (uint64 array of pointers to ASCII blocks the
+        caller keeps alive) and one length byte per read (FqReader::reads[f] / rlengths[f])."""
+        assert read_ptrs.dtype == np.uint64 and read_ptrs.flags.c_contiguous and rlengths.dtype == np.uint8
+        o = out or _CountsOut(n_genomes, self.n_leaves, pair_cap)
+        _check(lib().cq_query_reads(self._h, mode, _p(read_ptrs), _p(rlengths), len(rlengths), n_genomes, C.byref(o.c)))
         return o.result()
 
     def query_packed(self, packed: np.ndarray, lens: np.ndarray, max_len: int, n_genomes: int,
@@ -390,6 +405,12 @@ class Multi:
         offsets = np.ascontiguousarray(offsets, np.uint64)
         o = _CountsOut(n_genomes, self.n_leaves, pair_cap)
         _check(lib().cq_multi_query(self._h, mode, _p(bases), _p(offsets), len(offsets) - 1, n_genomes, C.byref(o.c)))
+        return o.result()
+
+    def query_reads(self, read_ptrs, rlengths, n_genomes, mode=MODE_P, pair_cap=1 << 16):
+        assert read_ptrs.dtype == np.uint64 and read_ptrs.flags.c_contiguous and rlengths.dtype == np.uint8
+        o = _CountsOut(n_genomes, self.n_leaves, pair_cap)
+        _check(lib().cq_multi_query_reads(self._h, mode, _p(read_ptrs), _p(rlengths), len(rlengths), n_genomes, C.byref(o.c)))
         return o.result()
 
     def query_packed(self, packed, lens, max_len, n_genomes, mode=MODE_P, pair_cap=1 << 16, out=None):

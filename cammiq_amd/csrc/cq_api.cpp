@@ -161,6 +161,55 @@ struct WidenPool {
     }
 };
 
+// Host threads that sleep between chunks and pack ASCII reads into a chunk's page-locked rows (the ASCII doors of the host-fed
+// pipeline).  Started once per handle: spawning 32 threads per 2 M-read chunk cost ~1 ms of the ~4 ms a chunk took.
+// run(fn): fn(worker, n_workers) on every worker and on the calling thread (worker 0); returns when all are through.
+struct PackPool {
+    std::vector<std::thread> th;
+    std::mutex mu;
+    std::condition_variable cv;
+    uint64_t job_seq = 0;
+    bool quit = false;
+    const std::function<void(unsigned, unsigned)> *job = nullptr;
+    std::atomic<uint32_t> done{0};
+
+    void loop(unsigned me)
+    {
+        uint64_t seen = 0;
+        for (;;) {
+            const std::function<void(unsigned, unsigned)> *j;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return quit || job_seq != seen; });
+                if (quit) return;
+                seen = job_seq;
+                j = job;
+            }
+            (*j)(me, (unsigned)th.size() + 1u);
+            done.fetch_add(1, std::memory_order_release);
+        }
+    }
+    void start(unsigned workers)   // workers besides the caller
+    {
+        for (unsigned t = 0; t < workers; t++) th.emplace_back([this, t] { loop(t + 1u); });
+    }
+    void run(const std::function<void(unsigned, unsigned)> &fn)
+    {
+        done.store(0, std::memory_order_relaxed);
+        { std::lock_guard<std::mutex> lk(mu); job = &fn; job_seq++; }
+        cv.notify_all();
+        fn(0u, (unsigned)th.size() + 1u);
+        while (done.load(std::memory_order_acquire) != th.size()) _mm_pause();
+    }
+    void stop()
+    {
+        { std::lock_guard<std::mutex> lk(mu); quit = true; }
+        cv.notify_all();
+        for (auto &x : th) x.join();
+        th.clear();
+    }
+};
+
 // CAMMIQ_PIPE_TRACE=<file>: timeline of one host-fed query from the library's own HIP events (timing enabled) and host
 // clock -- what rocprofv3 cannot give here: under its tracer the kernels of different streams no longer overlap and the
 // bracket grows from 26 to 32 ms.  Every mark is (name, chunk, stream event | host time); the file lists them relative
@@ -296,6 +345,7 @@ struct cq_index {
     uint2 *h_esc = nullptr; uint32_t *h_esc_count = nullptr;
     hipEvent_t ev_narrow = nullptr;
     WidenPool *pool = nullptr;
+    PackPool *pack_pool = nullptr;   // ASCII doors: packers of the host-fed pipeline (ensure_pack_pool)
     bool narrow_inflight = false;              // narrow_start has queued the kernel and woken the pool; narrow_finish collects
     uint64_t narrow_nseg = 0;
     PipeTrace *trace = nullptr;                // CAMMIQ_PIPE_TRACE: the query being traced (classify_range .. fetch_counts)
@@ -369,6 +419,7 @@ void release_device(cq_index *ix)
     if (ix->d_ctr) (void)hipFree(ix->d_ctr);
     if (ix->d_rc) (void)hipFree(ix->d_rc);
     if (ix->pool) { ix->pool->stop(); delete ix->pool; ix->pool = nullptr; }
+    if (ix->pack_pool) { ix->pack_pool->stop(); delete ix->pack_pool; ix->pack_pool = nullptr; }
     if (ix->d_rc8) (void)hipFree(ix->d_rc8);
     if (ix->d_esc) (void)hipFree(ix->d_esc);
     if (ix->d_esc_count) (void)hipFree(ix->d_esc_count);
@@ -1217,6 +1268,7 @@ void warm_workspace(cq_index *ix, LoadTimer *lt)
 struct Feed {
     const uint8_t *bases = nullptr;
     const uint64_t *offsets = nullptr;
+    const uint8_t *const *ptrs = nullptr;   // ASCII reads as one pointer + one length byte (lens) per read: FqReader's own arrays
     const uint32_t *packed = nullptr;
     const uint8_t *tight = nullptr;   // rows at a byte stride of sb (cq_pack_reads_tight); sw = ceil(sb / 4)
     const uint8_t *lens = nullptr;
@@ -1237,6 +1289,27 @@ int query_checks(const cq_index *ix, int mode, uint32_t n_genomes, const cq_coun
 }
 
 int narrow_start(cq_index *ix, uint64_t n_u, uint64_t n_d, uint32_t *dst_u, uint32_t *dst_d, const uint32_t *src = nullptr);   // below (rcount's narrow way back)
+
+unsigned pack_threads()
+{
+    if (const char *v = getenv("CAMMIQ_PACK_THREADS")) return (unsigned)std::min(64, std::max(1, atoi(v)));   // tuning knob (<= 64: per-worker result slots)
+    const unsigned hw = std::thread::hardware_concurrency();
+    return std::max(1u, std::min(hw ? hw : 1u, 32u));
+}
+
+// The handle's packers (nullptr: none to be had -- the caller packs on its own thread).
+PackPool *ensure_pack_pool(cq_index *ix)
+{
+    const unsigned want = pack_threads();
+    if (ix->pack_pool && ix->pack_pool->th.size() + 1 != want) { ix->pack_pool->stop(); delete ix->pack_pool; ix->pack_pool = nullptr; }   // knob changed
+    if (!ix->pack_pool) {
+        PackPool *p = new (std::nothrow) PackPool();
+        if (!p) return nullptr;
+        try { p->start(want - 1); } catch (...) { p->stop(); delete p; return nullptr; }
+        ix->pack_pool = p;
+    }
+    return ix->pack_pool;
+}
 
 // Classify reads [lo, hi) of `f` on ix's device into the handle's own counter block (d_ctr) and
 // rcount array (d_rc), both zeroed first: resetCounters + query64_* (query.cpp:1820-1840, 458-1080).
@@ -1288,6 +1361,9 @@ int classify_range(cq_index *ix, int mode, const Feed &f, uint64_t lo, uint64_t 
     CQ_HIP(hipEventRecord(ix->ev_zeroed, ix->s_comp));
     if (two) CQ_HIP(hipStreamWaitEvent(ix->s_comp2, ix->ev_zeroed, 0));
     const bool ascii = f.packed == nullptr && f.tight == nullptr;
+    const cq::ReadSource ascii_src{f.bases, f.offsets, f.ptrs, f.ptrs ? f.lens : nullptr};
+    PackPool *packers = ascii ? ensure_pack_pool(ix) : nullptr;
+    auto on_packers = [&](const std::function<void(unsigned, unsigned)> &fn) { if (packers) packers->run(fn); else fn(0u, 1u); };
     int rc = CQ_OK;
     uint64_t c = 0;
     PipeTrace *tr = ix->trace;
@@ -1349,23 +1425,16 @@ int classify_range(cq_index *ix, int mode, const Feed &f, uint64_t lo, uint64_t 
         const uint64_t n = sched[ci];
         uint64_t max_len = f.max_len;
         uint32_t sw = f.sw;
-        if (ascii) {   // longest read of the chunk (sizes the rows): a few threads, one would take ~1 ms per 2 M reads
-            const unsigned nt = n >= (1u << 18) ? 8u : 1u;
-            uint64_t part[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            auto scan = [&](unsigned t) {
-                uint64_t m = 0;
-                for (uint64_t r = c0 + n * t / nt, e = c0 + n * (t + 1) / nt; r < e; r++) {
-                    const uint64_t l = f.offsets[r + 1] - f.offsets[r];
-                    if (l <= 255 && l > m) m = l;
-                }
+        uint32_t sbc = f.sb;   // byte stride of this chunk's tight rows
+        if (ascii) {   // longest read of the chunk (sizes the rows): on the packers, one thread would take ~1 ms per 2 M reads
+            uint32_t part[64] = {0};
+            on_packers([&](unsigned t, unsigned nt) {
+                const uint32_t m = cq::longest_read(ascii_src, c0 + n * t / nt, c0 + n * (t + 1) / nt);
                 part[t] = m;
-            };
-            std::vector<std::thread> th;
-            for (unsigned t = 1; t < nt; t++) th.emplace_back(scan, t);
-            scan(0);
-            for (auto &x : th) x.join();
-            max_len = *std::max_element(part, part + nt);
+            });
+            max_len = *std::max_element(part, part + 64);
             sw = cq_pack_stride_words((uint32_t)max_len);
+            sbc = cq_pack_stride_bytes((uint32_t)max_len);
         }
         thost("slot_wait", c);
         if (sl.done) { CQ_HIPB(hipEventSynchronize(sl.done)); }   // the kernel that last used this slot
@@ -1374,11 +1443,26 @@ int classify_range(cq_index *ix, int mode, const Feed &f, uint64_t lo, uint64_t 
         if (rc != CQ_OK) break;
         const uint32_t *src_rows = nullptr;
         const uint8_t *src_lens = nullptr;
+        uint32_t ascii_mn = 255, ascii_mx = 0;
         if (ascii) {
-            uint64_t sk = 0;
-            rc = cq_pack_reads(f.bases, f.offsets + c0, n, img.hash_len, sw, sl.h_packed, sl.h_lens, &sk);
-            if (rc != CQ_OK) { fail(rc, "cq_pack_reads failed"); break; }
-            src_rows = sl.h_packed;
+            // ASCII -> TIGHT rows (ceil(longest / 4) bytes per read) straight into the slot's page-locked buffer, on the handle's
+            // packers; from here on the chunk is a tight-row chunk (25 instead of 28 bytes per 100-bp read on the link, widened by
+            // the classify kernel's own staging)
+            uint8_t *rows = (uint8_t *)sl.h_packed;   // n * sw words were reserved: >= n * sbc bytes
+            uint32_t mn[64], mx[64];
+            for (int i = 0; i < 64; i++) { mn[i] = 255; mx[i] = 0; }
+            thost("pack_begin", c);
+            on_packers([&](unsigned t, unsigned nt) {
+                const uint64_t a = n * t / nt, b = n * (t + 1) / nt;
+                uint64_t sk = 0;
+                uint32_t lo_len = 255, hi_len = 0;
+                cq::pack_tight_slice(ascii_src, c0 + a, c0 + b, img.hash_len, sbc, rows + a * sbc, sl.h_lens + a, &sk, &lo_len, &hi_len);
+                if (a == b) return;
+                mn[t] = lo_len; mx[t] = hi_len;
+            });
+            thost("pack_end", c);
+            ascii_mn = *std::min_element(mn, mn + 64);
+            ascii_mx = *std::max_element(mx, mx + 64);
             src_lens = sl.h_lens;
         } else {
             src_rows = f.tight ? nullptr : f.packed + (size_t)c0 * sw;
@@ -1387,16 +1471,17 @@ int classify_range(cq_index *ix, int mode, const Feed &f, uint64_t lo, uint64_t 
         // (Rows in pageable memory are handed to the runtime as they are: staging them through the slot's page-locked
         // buffer with eight memcpy threads made the packed door 10 % faster and the cammiq shell's query 3-5 ms slower
         // -- same box, A/B/A/B -- so it is not done.)
-        const uint8_t *src_tight = f.tight ? f.tight + (size_t)c0 * f.sb : nullptr;
-        if (f.tight) {   // fewer bytes over the link: the rows arrive tight and are widened on the device
-            if (sl.cap_tight < (size_t)n * f.sb + 16) {   // + 16: the kernel's last lane reads whole 16-byte pieces
+        const uint8_t *src_tight = f.tight ? f.tight + (size_t)c0 * f.sb : (ascii ? (const uint8_t *)sl.h_packed : nullptr);
+        const bool tight_chunk = src_tight != nullptr;
+        if (tight_chunk) {   // fewer bytes over the link: the rows arrive tight and are widened on the device
+            if (sl.cap_tight < (size_t)n * sbc + 16) {   // + 16: the kernel's last lane reads whole 16-byte pieces
                 if (sl.d_tight) (void)hipFree(sl.d_tight);
                 sl.d_tight = nullptr; sl.cap_tight = 0;
-                CQ_HIPB(hipMalloc((void **)&sl.d_tight, (size_t)n * f.sb + 16));
-                sl.cap_tight = (size_t)n * f.sb + 16;
+                CQ_HIPB(hipMalloc((void **)&sl.d_tight, (size_t)n * sbc + 16));
+                sl.cap_tight = (size_t)n * sbc + 16;
             }
             tdev("h2d_begin", c, ix->s_copy);
-            CQ_HIPB(hipMemcpyAsync(sl.d_tight, src_tight, (size_t)n * f.sb, hipMemcpyHostToDevice, ix->s_copy));
+            CQ_HIPB(hipMemcpyAsync(sl.d_tight, src_tight, (size_t)n * sbc, hipMemcpyHostToDevice, ix->s_copy));
         } else {
             tdev("h2d_begin", c, ix->s_copy);
             CQ_HIPB(hipMemcpyAsync(sl.d_packed, src_rows, (size_t)n * sw * 4, hipMemcpyHostToDevice, ix->s_copy));
@@ -1418,6 +1503,10 @@ int classify_range(cq_index *ix, int mode, const Feed &f, uint64_t lo, uint64_t 
             max_len = std::max<uint64_t>(max_len, longest);
             const bool fill_off = getenv("CAMMIQ_LENS_FILL") && atoi(getenv("CAMMIQ_LENS_FILL")) == 0;   // A/B knob
             lens_uniform = shortest == longest && !fill_off;
+        } else {
+            longest = ascii_mx;
+            const bool fill_off = getenv("CAMMIQ_LENS_FILL") && atoi(getenv("CAMMIQ_LENS_FILL")) == 0;   // A/B knob
+            lens_uniform = ascii_mn == ascii_mx && !fill_off;
         }
         // the small copy of the lengths goes down its own queue: behind the rows it would put a bubble between
         // every two large transfers
@@ -1427,13 +1516,13 @@ int classify_range(cq_index *ix, int mode, const Feed &f, uint64_t lo, uint64_t 
         // Tight rows are widened by the classify kernel's own staging (a byte image of the sub-tile through LDS): no widening
         // kernel sharing the GPU with the classify kernels, no second copy of the rows in HBM.  CAMMIQ_FUSED_WIDEN=0: the
         // separate widening kernel on its high-priority queue, as before (A/B knob).
-        const bool fused = f.tight && !(getenv("CAMMIQ_FUSED_WIDEN") && atoi(getenv("CAMMIQ_FUSED_WIDEN")) == 0);
+        const bool fused = tight_chunk && !(getenv("CAMMIQ_FUSED_WIDEN") && atoi(getenv("CAMMIQ_FUSED_WIDEN")) == 0);
         if (fused) {
             CQ_HIPB(hipStreamWaitEvent(s_k, sl.copied, 0));
-        } else if (f.tight) {   // widen on a queue of its own: in front of the classify kernel it would cost the chunk ~0.1 ms
+        } else if (tight_chunk) {   // widen on a queue of its own: in front of the classify kernel it would cost the chunk ~0.1 ms
             CQ_HIPB(hipStreamWaitEvent(ix->s_widen, sl.copied, 0));
             tdev("widen_begin", c, ix->s_widen);
-            CQ_HIPB(cq::launch_widen_rows(sl.d_tight, f.sb, sl.d_packed, sw, n, ix->s_widen));
+            CQ_HIPB(cq::launch_widen_rows(sl.d_tight, sbc, sl.d_packed, sw, n, ix->s_widen));
             CQ_HIPB(hipEventRecord(sl.widened, ix->s_widen));
             tdev("widen_end", c, ix->s_widen);
             CQ_HIPB(hipStreamWaitEvent(s_k, sl.widened, 0));
@@ -1442,7 +1531,7 @@ int classify_range(cq_index *ix, int mode, const Feed &f, uint64_t lo, uint64_t 
         CQ_HIPB(hipStreamWaitEvent(s_k, sl.copied_lens, 0));
         tdev("kernel_begin", c, s_k);
         rc = query_device_impl(ix, mode, sl.d_packed, sl.d_lens, n, sw, (uint32_t)max_len, n_genomes, ix->d_ctr, d_rc, s_k,
-                               OvfRef{&sl.d_ovf_list, &sl.d_ovf_count, &sl.ovf_cap}, fused ? sl.d_tight : nullptr, fused ? f.sb : 0u);
+                               OvfRef{&sl.d_ovf_list, &sl.d_ovf_count, &sl.ovf_cap}, fused ? sl.d_tight : nullptr, fused ? sbc : 0u);
         if (rc != CQ_OK) break;
         CQ_HIPB(hipEventRecord(sl.done, s_k));
         tdev("kernel_end", c, s_k);
@@ -1741,6 +1830,18 @@ int cq_query(cq_index *ix, int mode, const uint8_t *bases, const uint64_t *offse
     Feed f;
     f.bases = bases;
     f.offsets = offsets;
+    return query_one(ix, mode, f, n_reads, n_genomes, out);
+}
+
+int cq_query_reads(cq_index *ix, int mode, const uint8_t *const *reads, const uint8_t *rlengths, uint64_t n_reads,
+                   uint32_t n_genomes, cq_counts *out)
+{
+    if (!ix || !out || (n_reads && (!reads || !rlengths))) return fail(CQ_ERR_ARG, "cq_query_reads: NULL argument");
+    int rc = query_checks(ix, mode, n_genomes, out, "cq_query_reads");
+    if (rc != CQ_OK) return rc;
+    Feed f;
+    f.ptrs = reads;
+    f.lens = rlengths;
     return query_one(ix, mode, f, n_reads, n_genomes, out);
 }
 
@@ -2089,6 +2190,16 @@ int cq_multi_query(cq_multi *m, int mode, const uint8_t *bases, const uint64_t *
     f.bases = bases;
     f.offsets = offsets;
     return multi_query(m, mode, f, n_reads, n_genomes, out, "cq_multi_query");
+}
+
+int cq_multi_query_reads(cq_multi *m, int mode, const uint8_t *const *reads, const uint8_t *rlengths, uint64_t n_reads,
+                         uint32_t n_genomes, cq_counts *out)
+{
+    if (!m || !out || (n_reads && (!reads || !rlengths))) return fail(CQ_ERR_ARG, "cq_multi_query_reads: NULL argument");
+    Feed f;
+    f.ptrs = reads;
+    f.lens = rlengths;
+    return multi_query(m, mode, f, n_reads, n_genomes, out, "cq_multi_query_reads");
 }
 
 int cq_multi_query_packed(cq_multi *m, int mode, const uint32_t *packed, const uint8_t *lens, uint64_t n_reads,

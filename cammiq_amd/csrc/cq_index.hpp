@@ -124,6 +124,18 @@ bool save_image(const std::string &file, const SourceStamp &src, double kpb_over
 bool load_image(const std::string &file, const SourceStamp &src, double kpb_override, uint32_t m_override,
                 uint64_t max_table_bytes, DecodedTable tab[2], FlatImage &img);
 
+// Where a host-fed query's ASCII reads lie (cq_pack.cpp): one buffer + offsets, or -- ptrs != nullptr -- one pointer and one
+// length byte per read (FqReader's reads[f] / rlengths[f], query.hpp:35-36).
+struct ReadSource {
+    const uint8_t *bases = nullptr;
+    const uint64_t *offsets = nullptr;
+    const uint8_t *const *ptrs = nullptr;
+    const uint8_t *lens = nullptr;
+};
+void pack_tight_slice(const ReadSource &src, uint64_t lo, uint64_t hi, uint32_t h, uint32_t sb, uint8_t *dst, uint8_t *lens_out,
+                      uint64_t *skipped, uint32_t *mn, uint32_t *mx);
+uint32_t longest_read(const ReadSource &src, uint64_t lo, uint64_t hi);
+
 // Host mirror of the device lookup (used by tests of the layout through the C ABI and by
 // build_image's self-check).  Returns the slot values for `key` (0,0 when absent).
 void image_lookup(const FlatImage &img, uint64_t key, uint32_t &val_u, uint32_t &val_d,

@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "../../include/cammiq_hip.h"
+#include "cq_index.hpp"
 
 namespace {
 
@@ -223,6 +224,49 @@ void pack_range_tight(const uint8_t *bases, const uint64_t *offsets, uint64_t lo
     }
     *skipped = sk;
 }
+
+}  // namespace
+
+// Reads [lo, hi) of a source -- one buffer + offsets (cq_query), or one pointer + one length byte per read, the arrays
+// FqReader::readFastq leaves (query.hpp:35-36; cq_query_reads) -- as tight rows dst[(r - lo) * sb ..], lens_out[r - lo].
+// *mn / *mx: the smallest and the largest length written (skipped reads count as 0).  For the host-fed pipeline's slices.
+namespace cq {
+void pack_tight_slice(const ReadSource &src, uint64_t lo, uint64_t hi, uint32_t h, uint32_t sb, uint8_t *dst, uint8_t *lens_out,
+                      uint64_t *skipped, uint32_t *mn, uint32_t *mx)
+{
+    const int isa = pack_isa();
+    uint64_t sk = 0;
+    uint32_t lo_len = 255, hi_len = 0;
+    for (uint64_t r = lo; r < hi; r++) {
+        uint8_t *row = dst + (r - lo) * (uint64_t)sb;
+        const uint8_t *s;
+        uint64_t len;
+        if (src.ptrs) { s = src.ptrs[r]; len = src.lens[r]; }
+        else { s = src.bases + src.offsets[r]; len = src.offsets[r + 1] - src.offsets[r]; }
+        uint32_t out_len = 0;
+        if (len < h || len > 255 || len > (uint64_t)sb * 4 || (!s && len)) { memset(row, 0, sb); sk++; }
+        else if (!pack_bytes(s, (uint32_t)len, row, sb, isa)) { memset(row, 0, sb); sk++; }
+        else out_len = (uint32_t)len;
+        lens_out[r - lo] = (uint8_t)out_len;
+        lo_len = out_len < lo_len ? out_len : lo_len;
+        hi_len = out_len > hi_len ? out_len : hi_len;
+    }
+    *skipped = sk;
+    *mn = lo_len;
+    *mx = hi_len;
+}
+
+// The longest length <= 255 among reads [lo, hi) (sizes the rows of a chunk).
+uint32_t longest_read(const ReadSource &src, uint64_t lo, uint64_t hi)
+{
+    uint64_t m = 0;
+    if (src.ptrs) { for (uint64_t r = lo; r < hi; r++) m = src.lens[r] > m ? src.lens[r] : m; }
+    else for (uint64_t r = lo; r < hi; r++) { const uint64_t l = src.offsets[r + 1] - src.offsets[r]; if (l <= 255 && l > m) m = l; }
+    return (uint32_t)m;
+}
+}  // namespace cq
+
+namespace {
 
 template <class Fn>
 uint64_t run_threads(uint64_t n_reads, Fn &&fn)

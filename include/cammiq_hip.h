@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define CQ_ABI_VERSION 5   /* 5: cq_calibrate, cq_rcount_fetch; 4: cq_last_launch_info; every host-fed SC-mode query starts from an empty pair map */
+#define CQ_ABI_VERSION 6   /* 6: cq_query_reads, cq_multi_query_reads (the reference's reads[] / rlengths[] as they are); 5: cq_calibrate, cq_rcount_fetch; 4: cq_last_launch_info; every host-fed SC-mode query starts from an empty pair map */
 
 /*
  * Design limits of one handle (= one GPU's replica of the index).  The reference's pointer trie has none beyond its
@@ -166,6 +166,16 @@ typedef struct cq_counts {
  */
 int cq_query(cq_index *idx, int mode, const uint8_t *bases, const uint64_t *offsets,
              uint64_t n_reads, uint32_t n_genomes, cq_counts *out);
+
+/*
+ * The same call on the reference's own two arrays, as they are: reads[r] = one heap block of ASCII per read (no
+ * terminator), rlengths[r] = its length -- FqReader::reads[f].data() and FqReader::rlengths[f].data() (query.hpp:35-36,
+ * filled by readFastq, query.cpp:371-393).  Nothing is flattened or copied on the caller's side: the library's packer
+ * threads read every block where it lies and write 2-bit rows into page-locked chunks while the GPU classifies the
+ * previous chunk.  Same results as cq_query on the same reads; a NULL block of non-zero length is skipped (nskipped).
+ */
+int cq_query_reads(cq_index *idx, int mode, const uint8_t *const *reads, const uint8_t *rlengths,
+                   uint64_t n_reads, uint32_t n_genomes, cq_counts *out);
 
 /*
  * Same call for reads the host has already packed with cq_pack_reads (packed + lens, row stride
@@ -347,6 +357,8 @@ cq_index *cq_multi_index(cq_multi *m, int i);
 /* cq_query / cq_query_packed over all devices of m; same arguments, same results. */
 int cq_multi_query(cq_multi *m, int mode, const uint8_t *bases, const uint64_t *offsets,
                    uint64_t n_reads, uint32_t n_genomes, cq_counts *out);
+int cq_multi_query_reads(cq_multi *m, int mode, const uint8_t *const *reads, const uint8_t *rlengths,
+                         uint64_t n_reads, uint32_t n_genomes, cq_counts *out);
 int cq_multi_query_packed(cq_multi *m, int mode, const uint32_t *packed, const uint8_t *lens,
                           uint64_t n_reads, uint32_t stride_words, uint32_t max_len, uint32_t n_genomes,
                           cq_counts *out);

@@ -47,7 +47,11 @@ struct FqReader {
     cq_index *gpu_idx = NULL;
     std::vector<pleafNode> gpu_leaves[2];
     int loadIdx_gpu(int device);
-    int query64_gpu(const std::vector<uint8_t> &bases, const std::vector<uint64_t> &offs, int mode);
+    int query64_gpu(size_t file_idx, int mode);
+    // ---- the reads as FqReader::readFastq leaves them (query.hpp:35-36, query.cpp:371-393): one heap block per read, no
+    //      terminator, and its length in a byte
+    std::vector<uint8_t *> reads[1];
+    std::vector<uint8_t> rlengths[1];
 };
 
 // FqReader::loadIdx_gpu -- replaces loadIdx_p (query.cpp:109-123)
@@ -64,7 +68,7 @@ int FqReader::loadIdx_gpu(int device)
 }
 
 // FqReader::query64_gpu -- replaces query64_p / query64mt_p / query64_sc
-int FqReader::query64_gpu(const std::vector<uint8_t> &bases, const std::vector<uint64_t> &offs, int mode)
+int FqReader::query64_gpu(size_t file_idx, int mode)
 {
     const size_t G = genomes.size() - 1;
     std::vector<uint64_t> cu(G + 1), cd(G + 1), pc(1 << 12);
@@ -74,7 +78,8 @@ int FqReader::query64_gpu(const std::vector<uint8_t> &bases, const std::vector<u
     c.cnt_u = cu.data(); c.cnt_d = cd.data();
     c.rcount_u = ru.empty() ? NULL : ru.data(); c.rcount_d = rd.empty() ? NULL : rd.data();
     c.pair_a = pa.data(); c.pair_b = pb.data(); c.pair_cnt = pc.data(); c.pair_cap = pc.size();
-    int rc = cq_query(gpu_idx, mode, bases.data(), offs.data(), offs.size() - 1, (uint32_t)G, &c);
+    // the two arrays as they are: nothing is flattened or copied on this side
+    int rc = cq_query_reads(gpu_idx, mode, reads[file_idx].data(), rlengths[file_idx].data(), reads[file_idx].size(), (uint32_t)G, &c);
     if (rc == CQ_ERR_LIMIT && c.n_pairs > pc.size()) {   // more pairs than the arrays hold: the library kept them
         pa.resize(c.n_pairs); pb.resize(c.n_pairs); pc.resize(c.n_pairs);
         c.pair_a = pa.data(); c.pair_b = pb.data(); c.pair_cnt = pc.data(); c.pair_cap = pc.size();
@@ -100,16 +105,17 @@ int main(int argc, char **argv)
     if (const char *msg = cq_glue::load_genome_meta(fq.IDXDIR, fq.genomes, fq.IDXFILED.empty())) { fputs(msg, stderr); return 3; }
     if (argc > 5) {
         std::ifstream in(argv[5]);
-        std::vector<uint8_t> bases;
-        std::vector<uint64_t> offs(1, 0);
         std::string line;
-        while (std::getline(in, line)) {
-            if (line.empty()) continue;
-            bases.insert(bases.end(), line.begin(), line.end());
-            offs.push_back(bases.size());
+        while (std::getline(in, line)) {   // readFastq's own bookkeeping: a block of exactly the read's length per read
+            if (line.empty() || line.size() > 255) continue;
+            uint8_t *blk = new uint8_t[line.size()];
+            memcpy(blk, line.data(), line.size());
+            fq.reads[0].push_back(blk);
+            fq.rlengths[0].push_back((uint8_t)line.size());
         }
         const int mode = (argc > 6 && !strcmp(argv[6], "SC")) ? CQ_MODE_SC : CQ_MODE_P;
-        if (fq.query64_gpu(bases, offs, mode) != CQ_OK) return 1;
+        if (fq.query64_gpu(0, mode) != CQ_OK) return 1;
+        for (uint8_t *blk : fq.reads[0]) delete[] blk;
     }
     // ---- the state runILP_* reads (query.cpp:1100-1226), in the order it iterates it
     printf("nundet %zu nconf %zu\n", fq.nundet, fq.nconf);

@@ -17,7 +17,7 @@ import pytest
 import cammiq_amd as cq
 from cammiq_amd import synth
 import oracle_lib
-from util import assert_same, build_index
+from util import assert_same, build_index, read_pointers
 
 pytestmark = pytest.mark.gpu
 
@@ -39,7 +39,7 @@ def _draw(seed):
              frac_random=r.choice([0.0, 0.1, 0.5]), lower_frac=r.choice([0.0, 0.2]),
              n_bad=r.choice([0, 0, 3, 40]), unique_only=r.random() < 0.2,
              extra_genomes=r.choice([0, 0, 1, 37, 8191, 9000]),          # ids the index never names; 9000 > LDS histogram
-             route=r.choice(["ascii", "ascii", "packed", "tight", "multi", "multi_packed", "multi_tight"]),
+             route=r.choice(["ascii", "reads", "packed", "tight", "multi", "multi_reads", "multi_packed", "multi_tight"]),
              env={})
     lo = max(h, 1)
     shape = r.choice(["fixed", "ragged", "short", "long"])
@@ -130,6 +130,12 @@ def _run_world(w, tmpdir):
                 tight, lens, sk = cq.pack_reads_tight(bm, om, w["h"])
                 assert sk == n_bad, f"tight packer skipped {sk}, want {n_bad}"
                 got = ix.query_packed_tight(tight, lens, 0, G, mode=mode)
+            elif w["route"].endswith("reads"):   # the reference's own arrays: a pointer and a length byte per read
+                short = [x for x in mixed if len(x) <= 255]
+                bs, os_ = synth.concat_reads(short)
+                ptrs, rl8 = read_pointers(bs, os_)
+                got = ix.query_reads(ptrs, rl8, G, mode=mode)
+                assert got["nskipped"] == n_bad - (len(mixed) - len(short)), f"nskipped {got['nskipped']}"
             else:
                 got = ix.query(bm, om, G, mode=mode)
                 assert got["nskipped"] == n_bad, f"nskipped {got['nskipped']}, want {n_bad}"
@@ -157,7 +163,7 @@ def _draw_generator(seed):
              genome_len=max(markers * me // G, 600), frac_deep=r.choice([0.0, 0.07, 0.5]),
              pair_share=r.choice([0.0, 0.1, 0.5]), block=r.choice([256, 2048, 8192]),
              n_reads=r.choice([20_000, 60_000]), err=r.choice([0.0, 0.01, 0.05]), frac_random=r.choice([0.0, 0.1, 0.6]),
-             route=r.choice(["ascii", "packed", "tight", "multi", "multi_packed", "multi_tight"]), env={})
+             route=r.choice(["ascii", "reads", "packed", "tight", "multi", "multi_reads", "multi_packed", "multi_tight"]), env={})
     w["rl"] = r.choice([h, 50, 75, 100, 100, 150, 250, 255])
     w["rl"] = min(max(w["rl"], h), w["genome_len"])
     if r.random() < 0.4:
@@ -207,6 +213,10 @@ def _run_generator_world(w, tmpdir):
                 tight, lens, sk = cq.pack_reads_tight(b, o, w["h"])
                 assert sk == 0
                 got = ix.query_packed_tight(tight, lens, w["rl"], G, mode=mode, pair_cap=1 << 18)
+            elif w["route"].endswith("reads"):
+                ptrs, rl8 = read_pointers(b, o)
+                got = ix.query_reads(ptrs, rl8, G, mode=mode, pair_cap=1 << 18)
+                assert got["nskipped"] == 0
             else:
                 got = ix.query(b, o, G, mode=mode, pair_cap=1 << 18)
                 assert got["nskipped"] == 0

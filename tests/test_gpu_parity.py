@@ -8,7 +8,7 @@ import pytest
 import cammiq_amd as cq
 from cammiq_amd import synth
 import oracle_lib
-from util import assert_same, build_index, golden
+from util import assert_same, build_index, golden, read_pointers
 
 pytestmark = pytest.mark.gpu
 
@@ -34,6 +34,44 @@ def test_golden_fixtures(name):
     assert int(sc["rcount_u"].sum()) == 0
     # a second call on the same handle overwrites, it does not accumulate
     assert_same(ix.query(b, o, g["G"]), g["exp"]["p"], name + " again")
+
+
+@pytest.mark.parametrize("name", ["f_deep", "f_flat"])
+def test_reads_door_takes_the_references_own_arrays(name):
+    """cq_query_reads: one pointer and one length byte per read -- FqReader::reads[f] / rlengths[f] as readFastq leaves
+    them (query.hpp:35-36, query.cpp:371-393), every read a heap block of its own.  Same counts as the flattened door and
+    as the golden vectors, in both modes, on one device and through cq_multi_query_reads; blocks shorter than h, blocks
+    with a byte outside ACGTacgt, empty blocks and a NULL block of length 0 are skipped, not read past."""
+    import ctypes
+    g = golden(name)
+    reads = list(g["reads"])
+    # every read in a buffer of its own, as the reference allocates them (no terminator, nothing valid behind the block)
+    blocks = [ctypes.create_string_buffer(r, len(r)) for r in reads]
+    ptrs = np.array([ctypes.addressof(b) for b in blocks], np.uint64)
+    rl8 = np.array([len(r) for r in reads], np.uint8)
+    ix = cq.Index(g["pu"], g["pd"], device=0)
+    got = ix.query_reads(ptrs, rl8, g["G"])
+    assert_same(got, g["exp"]["p"], name + " reads door")
+    assert got["nskipped"] == 0
+    b, o = synth.concat_reads(reads)
+    assert_same(ix.query(b, o, g["G"]), got, name + " flattened door")
+    sc = ix.query_reads(ptrs, rl8, g["G"], mode=cq.MODE_SC)
+    assert_same(sc, g["exp"]["sc"], name + " reads door sc", rcount=False)
+    assert sorted([a, b_, c] for (a, b_), c in sc["pairs"].items()) == g["exp"]["sc"]["pairs"]
+    # blocks outside the parity domain between the good ones: counts unchanged, every one of them in nskipped
+    h = ix.hash_len
+    bad = [b"", b"ACGT"[: max(0, min(4, h - 1))], b"N" * (h + 3), reads[0][:h - 1], reads[1][:h] + b"n" + reads[1][h + 1:]]
+    bad_blocks = [ctypes.create_string_buffer(x, max(1, len(x))) for x in bad]
+    p2 = list(ptrs[:100]) + [ctypes.addressof(x) for x in bad_blocks] + [0] + list(ptrs[100:])
+    l2 = list(rl8[:100]) + [len(x) for x in bad] + [0] + list(rl8[100:])
+    got2 = ix.query_reads(np.array(p2, np.uint64), np.array(l2, np.uint8), g["G"])
+    assert got2["nskipped"] == len(bad) + 1
+    assert_same(got2, g["exp"]["p"], name + " reads door with blocks outside the domain")
+    # several shards (the same device twice: a one-GPU box): cq_multi_query_reads cuts the pointer array, not a buffer
+    m = cq.Multi(g["pu"], g["pd"], [0, 0])
+    assert_same(m.query_reads(ptrs, rl8, g["G"]), g["exp"]["p"], name + " reads door, two shards")
+    m.close()
+    del blocks, bad_blocks
 
 
 def test_image_cache_gives_identical_results(tmp_path, monkeypatch):

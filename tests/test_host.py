@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name), f"{name} declared in cammiq_hip.h but not exported"
     assert declared == set(binding.SIGNATURES), (declared ^ set(binding.SIGNATURES))
-    assert binding.lib().cq_abi_version() == 5
+    assert binding.lib().cq_abi_version() == 6
 
 
 def test_oracle_is_not_linked_into_the_product():

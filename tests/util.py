@@ -58,3 +58,14 @@ def hmers_of_reads(bases: np.ndarray, n: int, rl: int, h: int) -> np.ndarray:
             hv = (hv << np.uint64(2)) | c[:, j:j + W].astype(np.uint64)
         out.append(hv.ravel())
     return np.unique(np.concatenate(out))
+
+
+def read_pointers(bases, offs):
+    """(bases, offsets) -> the arrays cq_query_reads takes: one address per read into `bases` (which the caller keeps alive)
+    and one length byte per read -- the shape of FqReader::reads[f] / rlengths[f] (query.hpp:35-36).  Reads longer than 255
+    cannot be expressed in a length byte (the reference's uint8_t wraps, query.cpp:387): the caller leaves them out."""
+    import numpy as np
+    lens = np.diff(offs.astype(np.int64))
+    assert lens.size == 0 or int(lens.max()) <= 255, "a length byte holds at most 255"
+    ptrs = (np.uint64(bases.ctypes.data) + offs[:-1].astype(np.uint64)).astype(np.uint64)
+    return np.ascontiguousarray(ptrs), np.ascontiguousarray(lens.astype(np.uint8))

@@ -45,5 +45,28 @@ pp = cq.host_array(pk.size, np.uint32).reshape(pk.shape); pp[:] = pk
 pl = cq.host_array(ln.size, np.uint8); pl[:] = ln
 t, _ = best(lambda: ix.query_packed(pp, pl, rl, G, out=out_pin))
 print(f"packed door, pinned in/out     {t * 1e3:8.1f} ms  {n / t / 1e6:8.1f} Mreads/s")
-t, _ = best(lambda: ix.query(b, o, G))
+t, r_ascii = best(lambda: ix.query(b, o, G))
 print(f"ASCII door (cq_query), pageable out {t * 1e3:8.1f} ms  {n / t / 1e6:8.1f} Mreads/s")
+t, _ = best(lambda: ix.query(b, o, G, out=out_pin))
+print(f"ASCII door (cq_query), pinned out   {t * 1e3:8.1f} ms  {n / t / 1e6:8.1f} Mreads/s")
+if hasattr(cq.binding.lib(), "cq_query_reads"):
+    # the reference's own arrays: every read a heap block of its own.  glibc hands consecutive `new uint8_t[100]` out 112 bytes
+    # apart (16-byte header, 16-byte granule): the arena below has that layout, reads[r] = arena + 112 r
+    stride = (rl + 8 + 15) // 16 * 16
+    arena = np.zeros(n * stride, np.uint8)
+    arena.reshape(n, stride)[:, :rl] = b.reshape(n, rl)
+    ptrs = (np.uint64(arena.ctypes.data) + np.arange(n, dtype=np.uint64) * np.uint64(stride)).astype(np.uint64)
+    rl8 = np.full(n, rl, np.uint8)
+    t, r_reads = best(lambda: ix.query_reads(ptrs, rl8, G))
+    print(f"reads door (cq_query_reads: one block per read, {stride} B apart), pageable out {t * 1e3:8.1f} ms  {n / t / 1e6:8.1f} Mreads/s")
+    t, _ = best(lambda: ix.query_reads(ptrs, rl8, G, out=out_pin))
+    print(f"reads door (cq_query_reads), pinned out {t * 1e3:8.1f} ms  {n / t / 1e6:8.1f} Mreads/s")
+    for k in ("cnt_u", "cnt_d", "rcount_u", "rcount_d"):
+        assert np.array_equal(r_ascii[k], r_reads[k]), k
+    assert (r_ascii["nundet"], r_ascii["nconf"]) == (r_reads["nundet"], r_reads["nconf"])
+    # what the stub of INTEGRATION.md did before this door existed: flatten reads[] on one thread, then cq_query
+    t0 = time.perf_counter()
+    flat = np.ascontiguousarray(arena.reshape(n, stride)[:, :rl]).reshape(-1)
+    t_flat = time.perf_counter() - t0
+    print(f"(flattening the blocks into one buffer first, numpy, one thread: {t_flat * 1e3:8.1f} ms)")
+    del flat
