@@ -35,7 +35,9 @@ parsing are outside, exactly like the reference's own `Time for query` (query.cp
 rate of the same workload -- tight 2-bit rows in pinned HOST memory, pipelined H2D + kernels,
 counters and rcount back in the caller's arrays through cq_query_packed_tight: SURVEY.md 8(d)'s
 bracket -- is reported next to it as `host_fed` / `value_survey_8d_bracket`.  `roofline.board`
-says what THIS board's memory system gives (cq_calibrate, ~0.15 s before the timed region).
+says what THIS board's memory system gives (cq_calibrate, ~0.15 s before the timed region).  `reads_door` is the rate
+through cq_query_reads on the bench sample: the reference's own reads[] / rlengths[] arrays (ASCII, pageable), host packing
+included -- what a binding that keeps readFastq gets.
 Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
@@ -255,6 +257,8 @@ def main():
         sample_bases = None
         ns = min(args.cpu_sample, n)
         h_packed, h_lens, d_packed, d_lens = [], [], [], []
+        # batch 0 also stays as what the reference holds after readFastq -- ASCII, pageable -- for the reads-door leg
+        ascii_all = np.empty(n * rl, np.uint8) if (host_fed and rank == 0) else None
         for j in range(nb):
             keep_host = host_fed and j == 0           # one batch in pinned host memory feeds the host-fed leg
             hp = cq.host_array(n * sb, np.uint8).reshape(n, sb) if keep_host else None   # tight rows: what crosses the link
@@ -273,6 +277,8 @@ def main():
                 if keep_host:
                     _, _, tsk = cq.pack_reads_tight(ascii_buf[:m * rl], offs, h, sb, out=(hp[c0:c0 + m], hl[c0:c0 + m]))
                     assert tsk == 0
+                    if ascii_all is not None:
+                        ascii_all[c0 * rl:(c0 + m) * rl] = ascii_buf[:m * rl]
                 dp[c0:c0 + m].copy_(torch.from_numpy(pk.view(np.int32)))
                 dl[c0:c0 + m].copy_(torch.from_numpy(ln))
             h_packed.append(hp); h_lens.append(hl); d_packed.append(dp); d_lens.append(dl)
@@ -558,6 +564,38 @@ def main():
                     raise SystemExit("multi-GPU (one process) counts differ from the single-device counts")
             except subprocess.TimeoutExpired:
                 result["multi_in_process"] = {"devices": list(range(ndev)), "error": "no result within the time limit (child killed)"}
+
+        if rank == 0 and world == 1 and host_fed and ascii_all is not None:
+            # the door a reference-side binding uses without touching readFastq: FqReader's own arrays, one
+            # pointer and one length byte per read, ASCII in pageable memory -- host packing + H2D + kernels + D2H, the whole
+            # batch the host-fed leg classified
+            ptrs = (np.uint64(ascii_all.ctypes.data) + np.arange(n, dtype=np.uint64) * np.uint64(rl)).astype(np.uint64)
+            rl8 = np.full(n, rl, np.uint8)
+            ix.query_reads(ptrs[:1000], rl8[:1000], G)
+            out_pg = ix.counts_out(G, pinned=False)    # a binding's std::vectors
+            out_pin = ix.counts_out(G, pinned=True)
+            tr, tp = [], []
+            for _ in range(2):
+                t0 = time.perf_counter()
+                rd = ix.query_reads(ptrs, rl8, G, out=out_pg)
+                tr.append(time.perf_counter() - t0)
+            for _ in range(2):
+                t0 = time.perf_counter()
+                ix.query_reads(ptrs, rl8, G, out=out_pin)
+                tp.append(time.perf_counter() - t0)
+            same = (int(rd["nundet"]) == int(hq["nundet"]) and int(rd["nconf"]) == int(hq["nconf"])
+                    and np.array_equal(rd["cnt_u"], hq["cnt_u"]) and np.array_equal(rd["cnt_d"], hq["cnt_d"])
+                    and np.array_equal(rd["rcount_u"], hq["rcount_u"]) and np.array_equal(rd["rcount_d"], hq["rcount_d"]))
+            if not same:
+                raise SystemExit("PARITY FAILURE: cq_query_reads disagrees with the host-fed door on the same batch")
+            result["reads_door"] = {"Mreads_s": round(n / min(tr) / 1e6, 2), "Mreads_s_pinned_outputs": round(n / min(tp) / 1e6, 2),
+                                    "reads": n, "runs_ms": [round(x * 1e3, 3) for x in tr], "runs_ms_pinned_outputs": [round(x * 1e3, 3) for x in tp],
+                                    "what": "cq_query_reads on the reference's own arrays (one pointer + one length byte per read, "
+                                            "ASCII in pageable host memory): host packing + H2D + kernels + D2H on the batch the "
+                                            "host-fed leg classified, into pageable arrays (a binding's std::vectors) and into "
+                                            "page-locked ones; counters equal to the host-fed door's"}
+            del rd, ptrs, rl8, out_pg, out_pin
+        ascii_all = None
 
         if rank == 0 and world == 1 and args.ascii_api and sample_bases is not None:
             so = np.arange(ns + 1, dtype=np.uint64) * np.uint64(rl)

@@ -42,6 +42,7 @@ def test_single_gpu_line():
     assert o["reads"] == 2 * 200000 and o["nskipped"] == 0
     assert j["host_fed"]["Mreads_s"] > 0 and j["host_fed"]["bytes_per_read_on_the_wire"] == 25
     assert j["value_survey_8d_bracket"] == j["host_fed"]["Mreads_s"]
+    assert j["reads_door"]["Mreads_s"] > 0 and j["reads_door"]["reads"] > 0
 
 
 def test_multi_leg_on_one_device():
