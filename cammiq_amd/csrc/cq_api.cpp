@@ -801,7 +801,17 @@ void drop_host_image(HostIndex &H)
     d->r1.swap(H.img.leaf_r1);
     d->r2.swap(H.img.leaf_r2);
     try {
-        std::thread([d = std::move(d)]() mutable { d.reset(); }).detach();   // the thread holds the only reference
+        std::thread([d = std::move(d)]() mutable {
+            // pages first, in steps under the shared side of the mmap lock: a query that starts meanwhile keeps page faulting
+            // (the cammiq shell's first query read 43 instead of 24 ms with one munmap per array running beside it)
+            cq::release_pages(d->k0.data(), d->k0.capacity() * sizeof(uint64_t));
+            cq::release_pages(d->k1.data(), d->k1.capacity() * sizeof(uint64_t));
+            cq::release_pages(d->vals.data(), d->vals.capacity() * sizeof(uint32_t));
+            cq::release_pages(d->nodes.data(), d->nodes.capacity() * sizeof(cq::Node));
+            cq::release_pages(d->r1.data(), d->r1.capacity() * sizeof(uint32_t));
+            cq::release_pages(d->r2.data(), d->r2.capacity() * sizeof(uint32_t));
+            d.reset();
+        }).detach();   // the thread holds the only reference
     } catch (...) {
         // could not start a thread: the closure died with the exception and freed everything here
     }

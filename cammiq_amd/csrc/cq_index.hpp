@@ -79,6 +79,8 @@ public:
 // Hint for a large, not yet touched heap block (a reserve()d vector, a new[] array): back it with transparent huge
 // pages where the host allows them.  The decoder alone first-touches 1.4 GB on one thread for configs[1]'s index.
 void advise_huge(const void *p, size_t bytes);
+// Before freeing a large block: its pages go back in steps that do not keep the rest of the process from page faulting.
+void release_pages(const void *p, size_t bytes);
 
 // Device-ready image.  Everything is plain arrays so upload is a handful of memcpys.
 struct FlatImage {

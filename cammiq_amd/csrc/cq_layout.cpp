@@ -45,6 +45,18 @@ void advise_huge(const void *p, size_t bytes)
     if (hi > lo) (void)madvise((void *)lo, hi - lo, MADV_HUGEPAGE);   // whole 2 MiB frames inside the block; a hint only
 }
 
+// Give the pages of a large block that is about to be freed back to the OS in 64 MiB steps.  madvise(MADV_DONTNEED) zaps
+// pages under the READ side of the process's mmap lock, the side page faults take too; the munmap / free that follows finds
+// nothing left to zap and holds the WRITE side for microseconds.  (One munmap of several GB holds the write side for its whole
+// duration: every page fault of the process -- a query's first touch of its output arrays -- waits behind it.)
+void release_pages(const void *p, size_t bytes)
+{
+    const uintptr_t page = 4096, step = 64u << 20;
+    if (!p || bytes < (32u << 20)) return;
+    const uintptr_t lo = ((uintptr_t)p + page - 1) / page * page, hi = ((uintptr_t)p + bytes) / page * page;
+    for (uintptr_t a = lo; a < hi; a += step) (void)madvise((void *)a, std::min<uintptr_t>(step, hi - a), MADV_DONTNEED);
+}
+
 void HugeWords::alloc(size_t words)
 {
     reset();
@@ -70,6 +82,7 @@ void HugeWords::reset()
     // "streams 4831 ms" in the load timing, while the release thread was running); 256 MiB pieces hold it for
     // milliseconds each.
     if (base_) {
+        release_pages(base_, map_len_);
         const size_t piece = 256u << 20;
         size_t left = map_len_;
         while (left > piece) { left -= piece; (void)munmap((char *)base_ + left, piece); }
