@@ -74,6 +74,9 @@ constexpr int kWaves = kBlock / 64;
 #ifndef CQ_MAX_BLOCKS_PER_CU
 #define CQ_MAX_BLOCKS_PER_CU 6
 #endif
+#ifndef CQ_BIG_R
+#define CQ_BIG_R 8   /* reads per wave sub-tile of the "eight reads" instantiations (experiment builds: 16, with CQ_WAVES_PER_EU=3) */
+#endif
 #ifndef CQ_WIN_PER_LANE
 #define CQ_WIN_PER_LANE 5  /* consecutive windows one lane probes per pass: 100-bp reads, 8 per wave -> 120 lanes' worth = two passes */
 #endif
@@ -1148,18 +1151,18 @@ template <bool T>
 const void *variant_fn_t(int v)
 {
     switch (v) {
-    case kV8: return (const void *)classify_kernel<8, kFastCAP, false, 0, 0, 0, T>;
+    case kV8: return (const void *)classify_kernel<CQ_BIG_R, kFastCAP, false, 0, 0, 0, T>;
     case kV4: return (const void *)classify_kernel<4, kFastCAP, false, 0, 0, 0, T>;
-    case kV8h26r100: return (const void *)classify_kernel<8, kFastCAP, false, 26, 100, 16, T>;
-    case kV8h26r150: return (const void *)classify_kernel<8, kFastCAP, false, 26, 150, 16, T>;
-    case kV8h26r100m18: return (const void *)classify_kernel<8, kFastCAP, false, 26, 100, 18, T>;
-    case kV8h26r150m18: return (const void *)classify_kernel<8, kFastCAP, false, 26, 150, 18, T>;
-    case kV8h26s7: return (const void *)classify_kernel<8, kFastCAP, false, 26, -7, 16, T>;
-    case kV8h26s8: return (const void *)classify_kernel<8, kFastCAP, false, 26, -8, 16, T>;
-    case kV8h26s10: return (const void *)classify_kernel<8, kFastCAP, false, 26, -10, 16, T>;
-    case kV8h26s7m18: return (const void *)classify_kernel<8, kFastCAP, false, 26, -7, 18, T>;
-    case kV8h26s8m18: return (const void *)classify_kernel<8, kFastCAP, false, 26, -8, 18, T>;
-    case kV8h26s10m18: return (const void *)classify_kernel<8, kFastCAP, false, 26, -10, 18, T>;
+    case kV8h26r100: return (const void *)classify_kernel<CQ_BIG_R, kFastCAP, false, 26, 100, 16, T>;
+    case kV8h26r150: return (const void *)classify_kernel<CQ_BIG_R, kFastCAP, false, 26, 150, 16, T>;
+    case kV8h26r100m18: return (const void *)classify_kernel<CQ_BIG_R, kFastCAP, false, 26, 100, 18, T>;
+    case kV8h26r150m18: return (const void *)classify_kernel<CQ_BIG_R, kFastCAP, false, 26, 150, 18, T>;
+    case kV8h26s7: return (const void *)classify_kernel<CQ_BIG_R, kFastCAP, false, 26, -7, 16, T>;
+    case kV8h26s8: return (const void *)classify_kernel<CQ_BIG_R, kFastCAP, false, 26, -8, 16, T>;
+    case kV8h26s10: return (const void *)classify_kernel<CQ_BIG_R, kFastCAP, false, 26, -10, 16, T>;
+    case kV8h26s7m18: return (const void *)classify_kernel<CQ_BIG_R, kFastCAP, false, 26, -7, 18, T>;
+    case kV8h26s8m18: return (const void *)classify_kernel<CQ_BIG_R, kFastCAP, false, 26, -8, 18, T>;
+    case kV8h26s10m18: return (const void *)classify_kernel<CQ_BIG_R, kFastCAP, false, 26, -10, 18, T>;
     default: return (const void *)classify_kernel<kSlowR, kSlowCAP, true, 0, 0, 0>;   // the exact path reads tight rows byte by byte at run time
     }
 }
@@ -1213,7 +1216,7 @@ void launch_one(int variant, const DevIndex &ix, const QueryArgs &a, unsigned gr
 
 hipError_t launch_fast(int variant, const DevIndex &ix, QueryArgs &a, int n_cus, int per_cu, hipStream_t stream)
 {
-    const int R = (variant % kNVariants) == kV4 ? 4 : 8;
+    const int R = (variant % kNVariants) == kV4 ? 4 : CQ_BIG_R;
     const size_t sm = smem_bytes(R, kFastCAP, a, a.use_lds_hist);
     if (const char *v = getenv("CAMMIQ_BLOCKS_PER_CU")) per_cu = atoi(v);   // tuning knob
     if (per_cu < 1) per_cu = 1;
@@ -1289,19 +1292,19 @@ hipError_t launch_classify(const DevIndex &ix, QueryArgs a, int n_cus, hipStream
     //  * the instantiation with h = 26 and the batch's shape folded in, when index and batch are that shape.
     const bool hist_ok = lds_hist_fits(a.n_genomes), hist_forced = getenv("CAMMIQ_LDS_HIST_MAX") != nullptr;
     int r8 = 0, r4 = 0, r8h = 0, r4h = 0;
-    if ((e = fast_resident(dev, kV8, smem_bytes(8, kFastCAP, a, false), r8)) != hipSuccess ||
+    if ((e = fast_resident(dev, kV8, smem_bytes(CQ_BIG_R, kFastCAP, a, false), r8)) != hipSuccess ||
         (e = fast_resident(dev, kV4, smem_bytes(4, kFastCAP, a, false), r4)) != hipSuccess) return e;
-    if (hist_ok && ((e = fast_resident(dev, kV8, smem_bytes(8, kFastCAP, a, true), r8h)) != hipSuccess ||
+    if (hist_ok && ((e = fast_resident(dev, kV8, smem_bytes(CQ_BIG_R, kFastCAP, a, true), r8h)) != hipSuccess ||
                     (e = fast_resident(dev, kV4, smem_bytes(4, kFastCAP, a, true), r4h)) != hipSuccess)) return e;
     const int tv = a.tight ? kNVariants : 0;   // the instantiations that read tight rows
-    int R = (r8 <= 3 && r4 > r8) ? 4 : 8;   // measured: four reads per sub-tile cost 14 % at equal residency and 8 % at 6 against 5 workgroups (150 bp), and win 13 % at 6 against 3 (250 bp)
-    if (const char *v = getenv("CAMMIQ_FAST_R")) R = atoi(v) == 4 ? 4 : 8;   // tuning knob
-    const int plain = R == 8 ? r8 : r4, with = R == 8 ? r8h : r4h;
+    int R = (r8 <= 3 && r4 > r8) ? 4 : CQ_BIG_R;   // measured: four reads per sub-tile cost 14 % at equal residency and 8 % at 6 against 5 workgroups (150 bp), and win 13 % at 6 against 3 (250 bp)
+    if (const char *v = getenv("CAMMIQ_FAST_R")) R = atoi(v) == 4 ? 4 : CQ_BIG_R;   // tuning knob
+    const int plain = R == CQ_BIG_R ? r8 : r4, with = R == CQ_BIG_R ? r8h : r4h;
     a.use_lds_hist = hist_ok && (hist_forced || with >= plain) ? 1 : 0;
     int per_cu = a.use_lds_hist ? with : plain;
     int variant = R == 4 ? kV4 : kV8;
     const char *nofix = getenv("CAMMIQ_NO_FIXED_SHAPE");   // test / A-B knob: always the generic instantiation
-    if (R == 8 && ix.hash_len == 26 && (ix.minimizer_len == 16 || ix.minimizer_len == 18) && !(nofix && atoi(nofix))) {
+    if (R == CQ_BIG_R && ix.hash_len == 26 && (ix.minimizer_len == 16 || ix.minimizer_len == 18) && !(nofix && atoi(nofix))) {
         int fx = -1;
         const bool m18 = ix.minimizer_len == 18;
         // any batch of a common row stride keeps h, m and the stride as constants (101-, 125-, 151-bp reads: what real
@@ -1316,7 +1319,7 @@ hipError_t launch_classify(const DevIndex &ix, QueryArgs a, int n_cus, hipStream
         if (a.wmax == 150 - 26 + 1 && a.stride_words == 10) fx = m18 ? kV8h26r150m18 : kV8h26r150;
         if (fx >= 0) {
             int n = 0;   // same LDS layout as the generic kernel of this shape; its own register count
-            if ((e = fast_resident(dev, fx + tv, smem_bytes(8, kFastCAP, a, a.use_lds_hist != 0), n)) != hipSuccess) return e;
+            if ((e = fast_resident(dev, fx + tv, smem_bytes(CQ_BIG_R, kFastCAP, a, a.use_lds_hist != 0), n)) != hipSuccess) return e;
             if (n >= per_cu) { variant = fx; per_cu = n; }
         }
     }
