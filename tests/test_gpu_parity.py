@@ -67,6 +67,9 @@ def test_reads_door_takes_the_references_own_arrays(name):
     got2 = ix.query_reads(np.array(p2, np.uint64), np.array(l2, np.uint8), g["G"])
     assert got2["nskipped"] == len(bad) + 1
     assert_same(got2, g["exp"]["p"], name + " reads door with blocks outside the domain")
+    # no reads at all: every counter zero, nothing dereferenced
+    none = ix.query_reads(np.zeros(0, np.uint64), np.zeros(0, np.uint8), g["G"])
+    assert none["nundet"] == 0 and none["nconf"] == 0 and none["nskipped"] == 0 and not none["cnt_u"].any() and not none["rcount_u"].any()
     # several shards (the same device twice: a one-GPU box): cq_multi_query_reads cuts the pointer array, not a buffer
     m = cq.Multi(g["pu"], g["pd"], [0, 0])
     assert_same(m.query_reads(ptrs, rl8, g["G"]), g["exp"]["p"], name + " reads door, two shards")
