@@ -310,7 +310,7 @@ int main(int argc, char **argv)
             while (std::getline(ls, tok, ',')) if (!tok.empty()) dev_list.push_back(atoi(tok.c_str()));
             continue;
         }
-        if (v == "--image_cache") { setenv("CAMMIQ_IMAGE_CACHE", "1", 1); continue; }   // see cq_cache.cpp
+        if (v == "--image_cache") { setenv("CAMMIQ_IMAGE_CACHE", "1", 0); continue; }   // see cq_cache.cpp (an existing value, e.g. "force", stays)
         if (v == "--dump_counts") { dump = need(i, "Please specify the counts file name.\n"); continue; }
         if (v == "-h") {
             need(i, "Please specify the hash length.\n");

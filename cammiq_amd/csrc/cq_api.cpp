@@ -674,7 +674,20 @@ int prepare_host(const char *path_u, const char *path_d, double budget, std::sha
     const bool have_d = path_d && path_d[0];
     // Optional image cache next to index_u (cq_cache.cpp); the .bin files stay authoritative.
     const char *ce = getenv("CAMMIQ_IMAGE_CACHE");
-    const bool use_cache = ce && ce[0] == '1';
+    const bool cache_forced = ce && !strcmp(ce, "force");
+    bool use_cache = ce && (ce[0] == '1' || cache_forced);
+    // Estimate of the number of keys from the FILE SIZES: a bucket whose root is a leaf takes 8 + 6 (unique) or 8 + 12 (doubly
+    // unique) bytes of the byte stream, any other bucket more, so size / 14 + size / 20 bounds the keys from above.
+    double est_keys = 0.0;
+    {
+        struct stat su, sd;
+        if (stat(path_u, &su) == 0) est_keys += (double)su.st_size / 14.0;
+        if (have_d && stat(path_d, &sd) == 0) est_keys += (double)sd.st_size / 20.0;
+    }
+    // A handle on a GPU whose table is laid out THERE is ready sooner without the image than with it (configs[1]: 0.34-0.46 s
+    // against 0.56-0.93 s for reading 4 GB back): the cache serves handles without a device and tables the host builder lays
+    // out; CAMMIQ_IMAGE_CACHE=force keeps it for every handle.
+    if (use_cache && !cache_forced && for_device && gpu_layout_mode((uint64_t)est_keys)) use_cache = false;
     const std::string cache_file = std::string(path_u) + ".cqimg";
     cq::SourceStamp stamp;
     const bool stamped = use_cache && cq::stamp_sources(path_u, have_d ? path_d : "", stamp);
@@ -689,9 +702,8 @@ int prepare_host(const char *path_u, const char *path_d, double budget, std::sha
     int rc_u = CQ_OK, rc_d = CQ_OK;
     std::string err_u, err_d;
     // The table's block of HBM is asked for on a thread of its own (hipMalloc of 80 GB takes ~2 s, and every other
-    // allocation of the load queues behind it in the driver): before the decode, from the FILE SIZES -- a bucket whose root
-    // is a leaf takes 8 + 6 (unique) or 8 + 12 (doubly unique) bytes of the byte stream, any other bucket more, so
-    // size / 14 + size / 20 bounds the number of keys from above -- so that the block is there when the layout wants it.
+    // allocation of the load queues behind it in the driver): before the decode, from the file sizes' bound on the number of
+    // keys (est_keys above), so that the block is there when the layout wants it.
     // A block more than a tenth too large (an index of deep tries) is given back after the decode and asked for again.
     auto start_prealloc = [&](uint64_t n_table_buckets) {
         HostIndex *hp = H.get();
@@ -717,10 +729,7 @@ int prepare_host(const char *path_u, const char *path_d, double budget, std::sha
         return nbk + CQ_SPILL_TAIL;                  // ... + the spill tail
     };
     if (!from_cache && for_device && !stamped) {
-        struct stat su, sd;
-        double est = 0.0;
-        if (stat(path_u, &su) == 0) est += (double)su.st_size / 14.0;
-        if (have_d && stat(path_d, &sd) == 0) est += (double)sd.st_size / 20.0;
+        const double est = est_keys;
         double kpb_est;
         if (est >= 1e7 && gpu_layout_mode((uint64_t)est)) try { start_prealloc(table_buckets_for(est, kpb_est)); } catch (...) {}
     }

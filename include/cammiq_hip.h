@@ -102,7 +102,8 @@ typedef struct cq_index_info {
     uint64_t n_table_buckets;  /* 64-byte buckets in the device table (incl. spill tail) */
     uint64_t n_overflowed;     /* buckets whose overflow bit is set */
     uint32_t max_chain;        /* longest bucket chain a lookup can walk */
-    uint32_t reserved_;        /* 1 when the image came from the CAMMIQ_IMAGE_CACHE=1 file "<path_u>.cqimg" */
+    uint32_t reserved_;        /* 1 when the image came from the CAMMIQ_IMAGE_CACHE file "<path_u>.cqimg" (=1: handles without a device and
+                                  tables the host lays out; =force: every handle) */
     uint64_t device_bytes;     /* HBM held by this handle */
     uint32_t minimizer_len;    /* m-mer length the table is addressed by: 16, or 18 from 2.5e8 keys on (CQ_MINIMIZER_LARGE_FROM, cq_device.h) */
     uint32_t reserved2_;
