@@ -81,6 +81,33 @@ int main(int argc, char **argv)
         uint64_t tsk = 0;
         if (cq_pack_reads_tight(bases.data(), offs.data(), n, img.hash_len, sb, tight.data(), tl.data(), &tsk) != CQ_OK) { printf("PACK_READS_TIGHT FAILED\n"); return 1; }
     }
+    // the reads as the reference holds them (cq_query_reads' source): every read a heap block of EXACTLY its length, so that a
+    // load past a block's end is caught; rows of exactly n * sb bytes; must give the tight rows of the flattened source
+    {
+        std::vector<uint8_t *> blocks;
+        std::vector<uint8_t> bl;
+        std::vector<uint64_t> which;
+        for (uint64_t r = 0; r < n; r++) {
+            const uint64_t len = offs[r + 1] - offs[r];
+            if (len > 255) continue;
+            uint8_t *b = len ? new uint8_t[len] : nullptr;
+            if (len) memcpy(b, bases.data() + offs[r], len);
+            blocks.push_back(b); bl.push_back((uint8_t)len); which.push_back(r);
+        }
+        const uint64_t m = blocks.size();
+        const uint32_t sb = cq_pack_stride_bytes(255);
+        std::vector<uint8_t> rows(m * sb), rl(m), ref(n * sb + 1), reflen(n + 1);
+        cq::ReadSource src;
+        src.ptrs = blocks.data();
+        src.lens = bl.data();
+        uint64_t psk = 0, rsk = 0;
+        uint32_t mn = 0, mx = 0;
+        cq::pack_tight_slice(src, 0, m, img.hash_len, sb, rows.data(), rl.data(), &psk, &mn, &mx);
+        if (cq_pack_reads_tight(bases.data(), offs.data(), n, img.hash_len, sb, ref.data(), reflen.data(), &rsk) != CQ_OK) { printf("PACK_READS_TIGHT FAILED\n"); return 1; }
+        for (uint64_t i = 0; i < m; i++)
+            if (rl[i] != reflen[which[i]] || memcmp(rows.data() + i * sb, ref.data() + which[i] * sb, sb)) { printf("POINTER SOURCE DIFFERS at read %llu\n", (unsigned long long)which[i]); return 1; }
+        for (uint8_t *b : blocks) delete[] b;
+    }
     // meta files next to index_u (glue header): whatever is there -- present, absent or damaged -- must parse cleanly
     {
         std::vector<MetaGenome> genomes(std::min<uint64_t>((uint64_t)img.max_refid + 2, 100000));   // a damaged index may carry any refID
