@@ -228,9 +228,9 @@ void pack_range_tight(const uint8_t *bases, const uint64_t *offsets, uint64_t lo
 #if defined(__x86_64__)
 namespace {
 // pack_tight_slice for AVX2 hosts: the packer's constants stay in registers across the reads of a slice, a read's last
-// partial block is one more 32-base block over its LAST 32 bases when its length is a multiple of four (it overlaps what
-// the full blocks already wrote with the same bytes: 100 bp = blocks at 0, 32, 64 and 68), no scalar tail, no zero-fill of
-// bytes that are written anyway.  35 -> 19 ns per 100-bp read on one core of a 2.1 GHz Xeon; same bytes as pack_bytes.
+// partial block is one more 32-base block over the 32 bases that end at its last whole output byte (it overlaps what the
+// full blocks already wrote with the same bytes: 100 bp = blocks at 0, 32, 64 and 68; 150 bp = 0 .. 96 and 116, two bases
+// through the table), no zero-fill of bytes that are written anyway.  35 -> 19 ns per 100-bp read on one core of a 2.1 GHz Xeon; same bytes as pack_bytes.
 __attribute__((target("avx2"))) void pack_tight_slice_avx2(const cq::ReadSource &src, uint64_t lo, uint64_t hi, uint32_t h, uint32_t sb,
                                                              uint8_t *dst, uint8_t *lens_out, uint64_t *skipped, uint32_t *mn, uint32_t *mx)
 {
@@ -272,12 +272,26 @@ __attribute__((target("avx2"))) void pack_tight_slice_avx2(const cq::ReadSource 
                 memcpy(row + (j >> 2), &a, 4);
                 memcpy(row + (j >> 2) + 4, &b, 4);
             }
+            uint32_t sbad = 0;
+            if (j < len && len >= 32) {
+                // the 32 bases that END at the last whole output byte (e = len rounded down to a multiple of four): byte-aligned
+                // in the row, overlapping equal bytes of the full blocks (100 bp: blocks at 0, 32, 64 and 68; 150 bp: 0 .. 96, 116)
+                const uint32_t e = len & ~3u;
+                if (e > j) {
+                    CQ_PACK_BLOCK(s + e - 32, a, b);
+                    memcpy(row + ((e - 32) >> 2), &a, 4);
+                    memcpy(row + ((e - 32) >> 2) + 4, &b, 4);
+                    j = e;
+                }
+                if (j < len) {                          // one to three bases into the last byte
+                    uint32_t v = 0;
+                    for (uint32_t k = j; k < len; k++) { const uint32_t c = kSym.t[s[k]]; sbad |= c; v |= (c & 3u) << (6u - 2u * (k - j)); }
+                    row[j >> 2] = (uint8_t)v;
+                    j = len;
+                }
+            }
             if (j < len) {
-                if (len >= 32 && (len & 3u) == 0) {   // the last 32 bases: byte-aligned in the row, overlapping equal bytes
-                    CQ_PACK_BLOCK(s + len - 32, a, b);
-                    memcpy(row + ((len - 32) >> 2), &a, 4);
-                    memcpy(row + ((len - 32) >> 2) + 4, &b, 4);
-                } else {                               // a copy padded with 'A' (code 0: no bits, always valid)
+                {                                       // a read shorter than 32 bases: a copy padded with 'A' (code 0: no bits, always valid)
                     alignas(32) uint8_t pad[32];
                     memset(pad, 'A', 32);
                     memcpy(pad, s + j, len - j);
@@ -289,7 +303,7 @@ __attribute__((target("avx2"))) void pack_tight_slice_avx2(const cq::ReadSource 
                 }
             }
             if (nb < sb) memset(row + nb, 0, sb - nb);
-            if (!_mm256_testz_si256(bad, bad)) { memset(row, 0, sb); sk++; }
+            if (!_mm256_testz_si256(bad, bad) || (sbad & 0x80u)) { memset(row, 0, sb); sk++; }
             else out_len = len;
         }
         lens_out[r - lo] = (uint8_t)out_len;
