@@ -1438,6 +1438,7 @@ int classify_range(cq_index *ix, int mode, const Feed &f, uint64_t lo, uint64_t 
         });
     }
     uint64_t c0 = lo;
+    uint32_t ascii_next_longest = 0;   // ASCII feeds: the longest read of the chunk about to be packed
     for (size_t ci = 0; ci < sched.size() && rc == CQ_OK; c0 += sched[ci], ci++, c++) {
         cq_index::Slot &sl = ix->slot[c % kSlots];
         hipStream_t s_k = (two && (c & 1)) ? ix->s_comp2 : ix->s_comp;   // this chunk's kernels
@@ -1446,12 +1447,12 @@ int classify_range(cq_index *ix, int mode, const Feed &f, uint64_t lo, uint64_t 
         uint32_t sw = f.sw;
         uint32_t sbc = f.sb;   // byte stride of this chunk's tight rows
         if (ascii) {   // longest read of the chunk (sizes the rows): on the packers, one thread would take ~1 ms per 2 M reads
-            uint32_t part[64] = {0};
-            on_packers([&](unsigned t, unsigned nt) {
-                const uint32_t m = cq::longest_read(ascii_src, c0 + n * t / nt, c0 + n * (t + 1) / nt);
-                part[t] = m;
-            });
-            max_len = *std::max_element(part, part + 64);
+            if (ci == 0) {   // (every later chunk's was found by the job that packed the chunk before it)
+                uint32_t part[64] = {0};
+                on_packers([&](unsigned t, unsigned nt) { part[t] = cq::longest_read(ascii_src, c0 + n * t / nt, c0 + n * (t + 1) / nt); });
+                ascii_next_longest = *std::max_element(part, part + 64);
+            }
+            max_len = ascii_next_longest;
             sw = cq_pack_stride_words((uint32_t)max_len);
             sbc = cq_pack_stride_bytes((uint32_t)max_len);
         }
@@ -1468,20 +1469,22 @@ int classify_range(cq_index *ix, int mode, const Feed &f, uint64_t lo, uint64_t 
             // packers; from here on the chunk is a tight-row chunk (25 instead of 28 bytes per 100-bp read on the link, widened by
             // the classify kernel's own staging)
             uint8_t *rows = (uint8_t *)sl.h_packed;   // n * sw words were reserved: >= n * sbc bytes
-            uint32_t mn[64], mx[64];
-            for (int i = 0; i < 64; i++) { mn[i] = 255; mx[i] = 0; }
+            uint32_t mn[64], mx[64], nxt[64];
+            for (int i = 0; i < 64; i++) { mn[i] = 255; mx[i] = 0; nxt[i] = 0; }
+            const uint64_t n_next = ci + 1 < sched.size() ? sched[ci + 1] : 0, c_next = c0 + n;   // the same job sizes the next chunk's rows
             thost("pack_begin", c);
             on_packers([&](unsigned t, unsigned nt) {
                 const uint64_t a = n * t / nt, b = n * (t + 1) / nt;
                 uint64_t sk = 0;
                 uint32_t lo_len = 255, hi_len = 0;
                 cq::pack_tight_slice(ascii_src, c0 + a, c0 + b, img.hash_len, sbc, rows + a * sbc, sl.h_lens + a, &sk, &lo_len, &hi_len);
-                if (a == b) return;
-                mn[t] = lo_len; mx[t] = hi_len;
+                if (a != b) { mn[t] = lo_len; mx[t] = hi_len; }
+                if (n_next) nxt[t] = cq::longest_read(ascii_src, c_next + n_next * t / nt, c_next + n_next * (t + 1) / nt);
             });
             thost("pack_end", c);
             ascii_mn = *std::min_element(mn, mn + 64);
             ascii_mx = *std::max_element(mx, mx + 64);
+            ascii_next_longest = *std::max_element(nxt, nxt + 64);
             src_lens = sl.h_lens;
         } else {
             src_rows = f.tight ? nullptr : f.packed + (size_t)c0 * sw;
